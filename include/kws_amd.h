@@ -1,0 +1,145 @@
+/* kws_amd.h -- C ABI of the MI355X-native streaming GRU keyword-spotting path.
+ *
+ * Drop-in boundary.  Every entry point replaces one interface of the reference
+ * (paths relative to colinsongf/keyword_spotting):
+ *
+ *   kws_create / kws_destroy   tf.import_graph_def + tf.Session on the frozen DeployModel graph
+ *                              (detector.py:134-146; export list main.py:339-342)
+ *   kws_step                   sess.run(['model/softmax:0','model/logit:0','model/rnn_states:0'],
+ *                              {'model/inputX:0', 'model/rnn_initial_states:0'})
+ *                              (detector.py:190-193, :220-223, :280-283) on the mel-input variant
+ *                              of the graph (models/rnn_ctc.py:150-153), batched over B streams;
+ *                              arithmetic of models/rnn_ctc.py:155-165,202-284
+ *   kws_ctc_decode             utils/prediction.py:18 ctc_decode, :65 ctc_decode2, :89 ctc_decode_strict
+ *   kws_ctc_predict            utils/prediction.py:111 ctc_predict
+ *   kws_vad                    utils/basic_vad.py:17 vad
+ *   kws_octbit_matmul          REGISTER_OP("OctbitMatMul") octbit/octbit_ops_reg.cc:7-15,
+ *                              OctbitMatMulOp::Compute octbit/octbit_mat_mul_op.cc:49-183
+ *   kws_octbit_quantize        octize_weight_int8_signed octbit/octbit_graph.py:191-215
+ *
+ * Conventions
+ *   - plain C types only; every tensor pointer is CALLER-OWNED DEVICE memory (hipMalloc / a PyTorch
+ *     tensor's data_ptr) unless the parameter is documented as host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All work is
+ *     enqueued asynchronously on it; no entry point synchronises the device except kws_create /
+ *     kws_destroy / kws_kernel_times.
+ *   - return value: KWS_OK or a negative kws_status.  No exceptions, no abort.  The message for the
+ *     last failure on the calling thread is kws_last_error().
+ *   - a handle is immutable after kws_create except for its scratch buffer and profiling slots:
+ *     concurrent kws_step calls on ONE handle must be serialised by the caller (or use one handle
+ *     per host thread); different handles are independent.
+ */
+#ifndef KWS_AMD_H_
+#define KWS_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum kws_status {
+    KWS_OK = 0,
+    KWS_ERR_INVALID_ARGUMENT = -1, /* the TF InvalidArgumentError cases: bad dims, null ptr, K%64 ... */
+    KWS_ERR_UNSUPPORTED = -2,      /* shape outside what the kernels are built for                    */
+    KWS_ERR_HIP = -3,              /* a HIP runtime call failed (message has hipGetErrorString)       */
+    KWS_ERR_NO_DEVICE = -4,        /* no gfx950 device visible                                        */
+    KWS_ERR_OUT_OF_MEMORY = -5
+} kws_status;
+
+/* Model shape: config/rnn_config.py:57-99 (n_mel :63, hidden_size :84, num_layers :76,
+ * num_classes :88-91, use_relu :83, value_clip :80). */
+typedef struct kws_config {
+    int32_t n_mel;       /* I : mel bins per 10 ms frame                                   */
+    int32_t hidden;      /* H : GRU units per layer; supported: 64, 128, 256                */
+    int32_t num_layers;  /* L : 1..8                                                        */
+    int32_t num_classes; /* C : 3..8 (space, words..., blank)                               */
+    int32_t use_relu;    /* models/rnn_ctc.py:280                                           */
+    float value_clip;    /* models/rnn_ctc.py:282 : >0 and use_relu -> clip logits to [0,20] */
+} kws_config;
+
+typedef struct kws_model* kws_handle;
+
+enum { KWS_KERNEL_AUTO = 0, KWS_KERNEL_GENERIC = 1, KWS_KERNEL_RESIDENT = 2 };
+enum { KWS_DECODE = 0, KWS_DECODE2 = 1, KWS_DECODE_STRICT = 2 };
+
+const char* kws_version(void);
+/* Message of the last error raised on this thread ("" if none). */
+const char* kws_last_error(void);
+
+/* Bytes of the canonical fp32 weight blob for `cfg`:
+ *   per layer l (I_0 = n_mel, I_l = hidden):  Wg[I_l+H, 2H]  bg[2H]  Wc[I_l+H, H]  bc[H]
+ *   then Wfc[H, C]  bfc[C]           -- TF variable layouts, row-major, gate order [r, u]. */
+size_t kws_weights_nbytes(const kws_config* cfg);
+
+/* Stages the weights on the current HIP device (re-tiled into MFMA fragment order) and returns a
+ * handle.  `weights_blob` is HOST memory of kws_weights_nbytes(cfg) bytes. */
+int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, kws_handle* out);
+int kws_destroy(kws_handle h);
+
+/* Kernel family used by kws_step: AUTO picks the register-resident kernels when the shape allows
+ * (H == 128, I <= 128), else the generic ones.  RESIDENT on an unsupported shape -> KWS_ERR_UNSUPPORTED. */
+int kws_set_kernel(kws_handle h, int kind);
+/* Pre-sizes the inter-layer scratch for B streams x T frames so kws_step never allocates. */
+int kws_reserve(kws_handle h, int B, int T);
+
+/* Advances B independent streams by T frames (one 10 ms hop each).
+ *   mel        [B,T,I]  f32                          model/inputX:0 (mel variant), batch-major
+ *   state_in   [L,B,H]  f32                          model/rnn_initial_states:0
+ *   logits     [B,T,C]  f32   out, may be NULL       model/logit:0
+ *   softmax    [B,T,C]  f32   out, may be NULL       model/softmax:0
+ *   state_out  [L,B,H]  f32   out, may alias state_in  model/rnn_states:0
+ *   seq_len    [B] i32, may be NULL (= T): rows with t >= seq_len[b] keep their state and emit the
+ *              zero-output row (logits = bfc), as dynamic_rnn(sequence_length=...) does
+ *   reset_mask [B] u8,  may be NULL: non-zero -> stream b starts this call from the zero state and
+ *              prev_word = -1 (detector.py:313-316 clean_state + prob_queue.clear())
+ *   tokens     [B,T] i8 out, may be NULL: fused ctc_decode2 -- 0, or the word (1..C-2) emitted at
+ *              frame t (utils/prediction.py:74-80 with thres = decode2_thres)
+ *   prev_word  [B] i32 in/out, required iff tokens != NULL: ctc_decode2's pre_word carried across
+ *              calls (-1 = none)
+ * T == 0 or B == 0 is a no-op (state_out = state_in). */
+int kws_step(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
+             float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
+             int32_t* prev_word, float decode2_thres, int B, int T, void* stream);
+
+/* Per-kernel timing (bench.py roofline): when enabled, kws_step brackets each kernel launch with
+ * hipEvents on `stream`.  kws_kernel_times synchronises those events and returns, per layer kernel
+ * slot (0..L-1), the summed milliseconds and the launch count since the last reset. */
+int kws_set_profiling(kws_handle h, int enable);
+int kws_kernel_times(kws_handle h, float* ms_sum /*[L]*/, int32_t* launches /*[L]*/, int reset);
+
+/* Greedy CTC collapse over whole windows, one GPU thread per stream.
+ *   kind      KWS_DECODE (uses lockout, thres, loose_thres; columns 1:5 -> needs C >= 5),
+ *             KWS_DECODE2 (thres), KWS_DECODE_STRICT (lockout, thres)
+ *   softmax   [B,T,C] f32;  lengths [B] i32 or NULL (= T)
+ *   words     [B,max_words] i32 out: emitted words in order (without the interleaved zeros of the
+ *             reference's [0,w,0,...] format);  counts [B] i32 out (may exceed max_words: truncated) */
+int kws_ctc_decode(int kind, const float* softmax, const int32_t* lengths, int B, int T, int C,
+                   int lockout, float thres, float loose_thres, int32_t* words, int32_t* counts,
+                   int max_words, void* stream);
+
+/* ctc_predict: hit[b] = 1 iff the digits of label (host string of '1'..'9') occur contiguously in
+ * words[b, :min(counts[b], max_words)]. */
+int kws_ctc_predict(const int32_t* words, const int32_t* counts, int B, int max_words,
+                    const char* label, int32_t* hit, void* stream);
+
+/* vad: speech[b] = (sum_n |pcm[b,n]| > thres).  pcm [B,N] f32. */
+int kws_vad(const float* pcm, int B, int N, float thres, uint8_t* speech, float* abs_sum_or_null,
+            void* stream);
+
+/* OctbitMatMul: out[A,N] = (sum_k u8(x)[a,k] * Wq[n,k] - signed*bias[n]) * scale_w * s_x.
+ *   x [A,K] f32, Wq [N,K] s8 (pre-transposed), bias [N] f32, out [A,N] f32.  K % 64 == 0, scale_w > 0.
+ *   per_row_scale = 0: one dynamic activation range over the whole x (the reference op, whose A is
+ *   1 in streaming);  1: one range per row a (what a batch of independent streams needs to
+ *   reproduce the batch-1 result).  The u8*s8 pair sums saturate to int16 as _mm_maddubs_epi16 does. */
+int kws_octbit_matmul(const float* x, const int8_t* Wq, float scale_w, const float* bias, float* out,
+                      int A, int K, int N, int per_row_scale, void* stream);
+
+/* Host-side quantiser: W [K,N] f32 (host) -> Wq [N,K] s8 (host), *scale, bias [N] f32 (host). */
+int kws_octbit_quantize(const float* W, int K, int N, int8_t* Wq, float* scale, float* bias);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KWS_AMD_H_ */

@@ -1,0 +1,96 @@
+"""ctypes binding of libkws_amd.so (include/kws_amd.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkws_amd.so")
+
+KWS_OK = 0
+KWS_ERR_INVALID_ARGUMENT = -1
+KWS_ERR_UNSUPPORTED = -2
+KWS_ERR_HIP = -3
+KWS_ERR_NO_DEVICE = -4
+KWS_ERR_OUT_OF_MEMORY = -5
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_RESIDENT = 0, 1, 2
+DECODE, DECODE2, DECODE_STRICT = 0, 1, 2
+
+
+class KwsConfig(ctypes.Structure):
+    _fields_ = [("n_mel", ctypes.c_int32), ("hidden", ctypes.c_int32), ("num_layers", ctypes.c_int32),
+                ("num_classes", ctypes.c_int32), ("use_relu", ctypes.c_int32),
+                ("value_clip", ctypes.c_float)]
+
+
+class KwsError(RuntimeError):
+    """Base of the errors the C ABI reports."""
+
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "kws_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class InvalidArgumentError(KwsError, ValueError):
+    """Mirror of tf.errors.InvalidArgumentError on the reference's boundary."""
+
+
+class UnsupportedError(KwsError, NotImplementedError):
+    pass
+
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_SIGNATURES = {
+    "kws_version": (ctypes.c_char_p, []),
+    "kws_last_error": (ctypes.c_char_p, []),
+    "kws_weights_nbytes": (ctypes.c_size_t, [ctypes.POINTER(KwsConfig)]),
+    "kws_create": (_i, [ctypes.POINTER(KwsConfig), _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "kws_destroy": (_i, [_vp]),
+    "kws_set_kernel": (_i, [_vp, _i]),
+    "kws_reserve": (_i, [_vp, _i, _i]),
+    "kws_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "kws_set_profiling": (_i, [_vp, _i]),
+    "kws_kernel_times": (_i, [_vp, _vp, _vp, _i]),
+    "kws_ctc_decode": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp]),
+    "kws_ctc_predict": (_i, [_vp, _vp, _i, _i, ctypes.c_char_p, _vp, _vp]),
+    "kws_vad": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp]),
+    "kws_octbit_matmul": (_i, [_vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "kws_octbit_quantize": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing -- build it with `make -C keyword_spotting_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc == KWS_OK:
+        return
+    msg = load().kws_last_error().decode("utf-8", "replace")
+    if rc == KWS_ERR_INVALID_ARGUMENT:
+        raise InvalidArgumentError(rc, msg)
+    if rc == KWS_ERR_UNSUPPORTED:
+        raise UnsupportedError(rc, msg)
+    raise KwsError(rc, msg)
+
+
+def current_stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

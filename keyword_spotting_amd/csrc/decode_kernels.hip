@@ -1,0 +1,139 @@
+// Greedy CTC collapse, keyword decision and VAD on the GPU.
+//   ctc_decode / ctc_decode2 / ctc_decode_strict : utils/prediction.py:18-62, :65-86, :89-108
+//   ctc_predict                                   : utils/prediction.py:111-118
+//   vad                                           : utils/basic_vad.py:17-18
+// HBM-bound byte work: one thread walks one stream's [T,C] window (the lockout / loose-mode rules
+// are sequential in t); a warp-wide layout would buy nothing at 24 B per frame.
+#include "kws_internal.h"
+
+namespace kws {
+
+struct RowTop { float best; int arg; };
+
+// first maximum over columns lo..hi-1 of one softmax row
+__device__ __forceinline__ RowTop row_top(const float* row, int lo, int hi) {
+    RowTop r{row[lo], 0};
+    for (int c = lo + 1; c < hi; ++c)
+        if (row[c] > r.best) { r.best = row[c]; r.arg = c - lo; }
+    return r;
+}
+
+__global__ void ctc_decode_kernel(int kind, const float* __restrict__ softmax, const int32_t* __restrict__ lengths,
+                                  int B, int T, int C, int lockout, float thres, float loose_thres,
+                                  int32_t* __restrict__ words, int32_t* __restrict__ counts, int max_words) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int len = lengths ? lengths[b] : T;
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const float* sm = softmax + (size_t)b * T * C;
+    int32_t* out = words + (size_t)b * max_words;
+    int n = 0;
+    auto emit = [&](int wd) { if (n < max_words) out[n] = wd; ++n; };
+
+    if (kind == KWS_DECODE2) {               // word changes only, utils/prediction.py:74-80
+        int prev = -1;
+        for (int t = 0; t < len; ++t) {
+            const RowTop r = row_top(sm + (size_t)t * C, 1, C - 1);
+            const int wd = r.best > thres ? r.arg : -1;
+            if (wd >= 0 && wd != prev) emit(wd + 1);
+            prev = wd;
+        }
+    } else if (kind == KWS_DECODE_STRICT) {  // threshold + lockout, :97-103
+        int skip_until = 0;
+        for (int t = 0; t < len; ++t) {
+            if (t < skip_until) continue;
+            const RowTop r = row_top(sm + (size_t)t * C, 1, C - 1);
+            if (r.best > thres) { emit(r.arg + 1); skip_until = t + lockout; }
+        }
+    } else {                                 // ctc_decode with loose mode, :28-56 (columns 1:5)
+        int skip_until = 0, last_t = 0;
+        int h0 = 0, h1 = 0, h2 = 0;          // last three emitted words, h2 newest
+        bool loose = false;
+        for (int t = 0; t < len; ++t) {
+            if (t < skip_until) continue;
+            const float* row = sm + (size_t)t * C;
+            const RowTop r = row_top(row, 1, 5);
+            if (!loose) {
+                if (r.best > thres) {
+                    emit(r.arg + 1);
+                    h0 = h1; h1 = h2; h2 = r.arg + 1; last_t = t;
+                    skip_until = t + lockout;
+                    loose = (h0 == 1 && h1 == 2 && h2 == 3);
+                }
+                continue;
+            }
+            if (r.best < loose_thres) {
+                if (h2 != 3) { skip_until = t + lockout; loose = false; }
+            } else if (row[3] > loose_thres) {       // le4 = column 2 of the 1:5 slice
+                emit(3);
+                h0 = h1; h1 = h2; h2 = 3; last_t = t;
+                skip_until = t + lockout;
+                loose = false;
+            } else if (r.best > 0.6f && last_t + lockout < t) {
+                emit(r.arg + 1);
+                h0 = h1; h1 = h2; h2 = r.arg + 1; last_t = t;
+            }
+        }
+    }
+    counts[b] = n;
+}
+
+struct LabelDigits { int32_t d[16]; int n; };
+
+__global__ void ctc_predict_kernel(const int32_t* __restrict__ words, const int32_t* __restrict__ counts, int B,
+                                   int max_words, LabelDigits lab, int32_t* __restrict__ hit) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = counts[b];
+    n = n > max_words ? max_words : n;
+    const int32_t* w = words + (size_t)b * max_words;
+    int found = lab.n == 0 ? 1 : 0;
+    for (int i = 0; i + lab.n <= n && !found; ++i) {
+        bool ok = true;
+        for (int j = 0; j < lab.n; ++j) ok = ok && (w[i + j] == lab.d[j]);
+        found = ok ? 1 : 0;
+    }
+    hit[b] = found;
+}
+
+// one workgroup per stream: sum |x| in fp32 (wave shuffle + LDS), compare with the threshold
+__global__ void __launch_bounds__(256) vad_kernel(const float* __restrict__ pcm, int N, float thres,
+                                                  uint8_t* __restrict__ speech, float* __restrict__ abs_sum) {
+    const int b = blockIdx.x;
+    const float* x = pcm + (size_t)b * N;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) acc += fabsf(x[i]);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = (part[0] + part[1]) + (part[2] + part[3]);
+        speech[b] = total > thres ? 1 : 0;
+        if (abs_sum) abs_sum[b] = total;
+    }
+}
+
+hipError_t launch_ctc_decode(int kind, const float* softmax, const int32_t* lengths, int B, int T, int C,
+                             int lockout, float thres, float loose_thres, int32_t* words, int32_t* counts,
+                             int max_words, hipStream_t st) {
+    hipLaunchKernelGGL(ctc_decode_kernel, dim3((B + 63) / 64), dim3(64), 0, st, kind, softmax, lengths, B, T, C,
+                       lockout, thres, loose_thres, words, counts, max_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_ctc_predict(const int32_t* words, const int32_t* counts, int B, int max_words,
+                              const int32_t* label_digits, int label_len, int32_t* hit, hipStream_t st) {
+    LabelDigits lab;
+    for (int i = 0; i < 16; ++i) lab.d[i] = i < label_len ? label_digits[i] : 0;
+    lab.n = label_len;
+    hipLaunchKernelGGL(ctc_predict_kernel, dim3((B + 63) / 64), dim3(64), 0, st, words, counts, B, max_words, lab, hit);
+    return hipGetLastError();
+}
+
+hipError_t launch_vad(const float* pcm, int B, int N, float thres, uint8_t* speech, float* abs_sum, hipStream_t st) {
+    hipLaunchKernelGGL(vad_kernel, dim3(B), dim3(256), 0, st, pcm, N, thres, speech, abs_sum);
+    return hipGetLastError();
+}
+
+}  // namespace kws

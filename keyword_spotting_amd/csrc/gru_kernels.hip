@@ -1,0 +1,552 @@
+// Streaming GRU layer kernels for gfx950 (MI355X).
+//
+// Replaces, per launch, one layer of the TF while_loop the reference builds at
+// models/rnn_ctc.py:228-243 (GRUCell x L under MultiRNNCell + dynamic_rnn) and, in the last layer's
+// epilogue, models/rnn_ctc.py:247-284 (inference2: dense), :165 (softmax) and
+// utils/prediction.py:65-86 (ctc_decode2's per-frame rule).
+//
+// Mapping (see DESIGN.md "Kernels"):
+//   * one workgroup = 4 waves = 16 streams; the MFMA is v_mfma_f32_16x16x4_f32 with
+//     M = 16 output units, N = 16 streams, K = 4 input rows.  Orientation D[unit][stream]:
+//     A = weights (lane (g,i): W[k(g)][unit i]), B = activations (lane (g,s): act[s][k(g)]).
+//   * wave w owns units [32w, 32w+32) (two 16-unit tiles) of r, u, c and h'.
+//   * the K index is permuted so that the C/D register image of a tile IS the B operand of four
+//     k-chunks (kws_internal.h "xl" layout): h' feeds the next step with no transpose, only an
+//     8 KiB LDS exchange so that every wave sees all 128 units.
+//   * resident kernel: the layer's recurrent + candidate weights live in registers (AGPR side of
+//     the unified file, 192 + 2*KCX fragments per wave), the gate x-part in LDS; nothing but the
+//     mel / previous layer's h stream is read per step.
+//   * x-part MFMAs of frame t+1 are issued behind frame t's two barriers (software pipeline), so
+//     the LDS exchange latency overlaps independent matrix work.
+#include "kws_internal.h"
+
+namespace kws {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// sigma(x) = 1/(1+e^-x).  v_exp_f32 path: abs error <= 3e-7 on [-30,30]; saturates cleanly.
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+// tanh(x) = 1 - 2/(1+e^{2x}); abs error <= 3e-7, exact limits +-1.
+__device__ __forceinline__ float tanh_f(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+}
+__device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// ------------------------------------------------------------------------------------------------
+// Last-layer epilogue: sums the four waves' partial logits staged in LDS, applies relu/clip,
+// softmax and ctc_decode2's frame rule, and writes [B,T,C] rows.  Executed by wave 0 only:
+// lane = 4*stream + frame-in-block, so the previous frame's word is one __shfl_up away.
+//   stage: [4 waves][kFlushSteps][16 streams][8]   carry: [16] previous word per stream
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flush_logits(const GruLayerParams& p, const float* stage, int* carry,
+                                             int group, int t0, int n, int lane, bool final_flush) {
+    const int tt = lane & (kFlushSteps - 1);
+    const int s = lane >> 2;
+    const int b = group * kStreamsPerGroup + s;
+    const int C = p.C;
+    float lg[kMaxClasses];
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += stage[((w * kFlushSteps + tt) * 16 + s) * 8 + c];
+        lg[c] = v;
+    }
+    if (p.use_relu) {
+#pragma unroll
+        for (int c = 0; c < kMaxClasses; ++c) {
+            lg[c] = fmaxf(lg[c], 0.f);
+            if (p.value_clip > 0.f) lg[c] = fminf(lg[c], 20.f);
+        }
+    }
+    float m = lg[0];
+#pragma unroll
+    for (int c = 1; c < kMaxClasses; ++c) m = (c < C) ? fmaxf(m, lg[c]) : m;
+    float pr[kMaxClasses];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c) {
+        pr[c] = (c < C) ? expf(lg[c] - m) : 0.f;
+        sum += pr[c];
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < kMaxClasses; ++c) pr[c] *= inv;
+    // ctc_decode2 frame rule over classes 1..C-2 (utils/prediction.py:67,74-75): first maximum, strict >
+    int word = -1;
+    float best = -1.f;
+#pragma unroll
+    for (int c = 1; c < kMaxClasses - 1; ++c) {
+        if (c < C - 1 && pr[c] > best) { best = pr[c]; word = c - 1; }
+    }
+    if (!(best > p.decode_thres)) word = -1;
+    int prev = __shfl_up(word, 1);
+    if (tt == 0) prev = carry[s];
+    const int token = (word >= 0 && word != prev) ? word + 1 : 0;   // :76-80
+    if (tt == n - 1) carry[s] = word;
+    if (b < p.B && tt < n) {
+        const size_t row = (size_t)b * p.T + (t0 + tt);
+        if (p.logits) {
+#pragma unroll
+            for (int c = 0; c < kMaxClasses; ++c)
+                if (c < C) p.logits[row * C + c] = lg[c];
+        }
+        if (p.softmax) {
+#pragma unroll
+            for (int c = 0; c < kMaxClasses; ++c)
+                if (c < C) p.softmax[row * C + c] = pr[c];
+        }
+        if (p.tokens) p.tokens[row] = (int8_t)token;
+        if (final_flush && tt == n - 1 && p.prev_word) p.prev_word[b] = word;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident kernel, H = 128.  KCX = x-part k-chunks (ceil(I/4) for the first layer, 32 above it).
+// ------------------------------------------------------------------------------------------------
+template <int KCX, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gru_layer_resident(const GruLayerParams p) {
+    constexpr int H = 128, NT = 8, KCH = 32;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, g = lane >> 4, s = lane & 15;
+    const int group = blockIdx.x;
+    const int b_raw = group * kStreamsPerGroup + s;
+    const bool bvalid = b_raw < p.B;
+    const int b = bvalid ? b_raw : p.B - 1;
+    const int T = p.T;
+    const int n0 = 2 * w, n1 = 2 * w + 1;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* hbuf = reinterpret_cast<f32x4*>(smem);       // [NT][64]  h_{t-1}, xl layout
+    f32x4* rhbuf = hbuf + NT * 64;                       // [NT][64]  r (.) h_{t-1}
+    f32x4* wlds = rhbuf + NT * 64;                       // [4 waves][KCX][64] gate x-part: {r0,u0,r1,u1}
+    float* stage = reinterpret_cast<float*>(wlds + 4 * KCX * 64);   // LAST: [4][kFlushSteps][16][8]
+    int* carry = reinterpret_cast<int*>(stage + 4 * kFlushSteps * 16 * 8);  // LAST: [16]
+
+    // ---- stage weights: registers (recurrent + candidate) and LDS (gate x-part) ------------------
+    float wgh[2][2][KCH];   // [tile][r|u][k-chunk]  A fragments of Wg rows I..I+H
+    float wch[2][KCH];      // candidate, h-part
+    float wcx[2][KCX];      // candidate, x-part
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = 2 * w + j;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) wgh[j][q][kc] = p.wh[((n * 3 + q) * KCH + kc) * 64 + lane];
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) wch[j][kc] = p.wh[((n * 3 + 2) * KCH + kc) * 64 + lane];
+#pragma unroll
+        for (int kc = 0; kc < KCX; ++kc) wcx[j][kc] = p.wx[((n * 3 + 2) * KCX + kc) * 64 + lane];
+    }
+    for (int kc = 0; kc < KCX; ++kc) {
+        f32x4 v;
+        v.x = p.wx[((n0 * 3 + 0) * KCX + kc) * 64 + lane];
+        v.y = p.wx[((n0 * 3 + 1) * KCX + kc) * 64 + lane];
+        v.z = p.wx[((n1 * 3 + 0) * KCX + kc) * 64 + lane];
+        v.w = p.wx[((n1 * 3 + 1) * KCX + kc) * 64 + lane];
+        wlds[(w * KCX + kc) * 64 + lane] = v;
+    }
+    f32x4 bias_r[2], bias_u[2], bias_c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = 2 * w + j;
+        bias_r[j] = ld4(p.bias + 0 * H + n * 16 + 4 * g);
+        bias_u[j] = ld4(p.bias + 1 * H + n * 16 + 4 * g);
+        bias_c[j] = ld4(p.bias + 2 * H + n * 16 + 4 * g);
+    }
+    float wfc[2][4];
+    f32x4 bfc4 = splat4(0.f);
+    if (LAST) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wfc[j][e] = p.wfc[((2 * w + j) * 4 + e) * 64 + lane];
+        if (w == 0) bfc4 = ld4(p.bfc + 4 * g);
+    }
+
+    // ---- initial state ---------------------------------------------------------------------------
+    const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
+    const int len_s = p.seq_len ? p.seq_len[b] : T;
+    f32x4 hreg[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = 2 * w + j;
+        hreg[j] = do_reset ? splat4(0.f) : ld4(p.state_in + (size_t)b * H + n * 16 + 4 * g);
+        hbuf[n * 64 + lane] = hreg[j];
+    }
+    if (LAST && tid < 16) {
+        const int bb = group * kStreamsPerGroup + tid;
+        int pw = -1;
+        if (bb < p.B && p.prev_word && !(p.reset && p.reset[bb])) pw = p.prev_word[bb];
+        carry[tid] = pw;
+    }
+
+    // ---- x stream --------------------------------------------------------------------------------
+    const float* xrow = FIRST ? p.x_mel + (size_t)b * T * p.I : nullptr;
+    const float4* xprev = FIRST ? nullptr : p.x_prev + (size_t)group * T * NT * 64 + lane;
+    float xB[KCX];
+    auto load_x = [&](int t) {
+        if (FIRST) {
+#pragma unroll
+            for (int kc = 0; kc < KCX; ++kc) {
+                const int k = 4 * kc + g;
+                xB[kc] = (k < p.I) ? xrow[(size_t)t * p.I + k] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int nn = 0; nn < KCX / 4; ++nn) {
+                const float4 v = xprev[((size_t)t * NT + nn) * 64];
+                xB[4 * nn + 0] = v.x; xB[4 * nn + 1] = v.y; xB[4 * nn + 2] = v.z; xB[4 * nn + 3] = v.w;
+            }
+        }
+    };
+
+    f32x4 acc_r[2], acc_u[2], acc_c[2];
+    auto gates_x = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
+#pragma unroll
+        for (int kc = 0; kc < KCX; ++kc) {
+            const f32x4 a4 = wlds[(w * KCX + kc) * 64 + lane];
+            acc_r[0] = mfma4(a4.x, xB[kc], acc_r[0]);
+            acc_u[0] = mfma4(a4.y, xB[kc], acc_u[0]);
+            acc_r[1] = mfma4(a4.z, xB[kc], acc_r[1]);
+            acc_u[1] = mfma4(a4.w, xB[kc], acc_u[1]);
+        }
+    };
+    auto cand_x = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_c[j] = bias_c[j];
+#pragma unroll
+        for (int kc = 0; kc < KCX; ++kc) {
+            acc_c[0] = mfma4(wcx[0][kc], xB[kc], acc_c[0]);
+            acc_c[1] = mfma4(wcx[1][kc], xB[kc], acc_c[1]);
+        }
+    };
+
+    __syncthreads();
+    if (T > 0) {
+        load_x(0);
+        gates_x();
+        cand_x();
+    }
+
+    for (int t = 0; t < T; ++t) {
+        // x of frame t+1: in flight while this frame's recurrent half runs
+        load_x(t + 1 < T ? t + 1 : T - 1);
+
+        // gates, h-part:  acc_{r,u} += Wg[I:,:]^T h_{t-1}
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            const f32x4 hb = hbuf[nn * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kc = 4 * nn + e;
+                acc_r[0] = mfma4(wgh[0][0][kc], hb[e], acc_r[0]);
+                acc_u[0] = mfma4(wgh[0][1][kc], hb[e], acc_u[0]);
+                acc_r[1] = mfma4(wgh[1][0][kc], hb[e], acc_r[1]);
+                acc_u[1] = mfma4(wgh[1][1][kc], hb[e], acc_u[1]);
+            }
+        }
+        f32x4 u[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 rh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rh[e] = sigmoid_f(acc_r[j][e]) * hreg[j][e];
+                u[j][e] = sigmoid_f(acc_u[j][e]);
+            }
+            rhbuf[(2 * w + j) * 64 + lane] = rh;
+        }
+        gates_x();            // frame t+1, independent of the exchange below
+        __syncthreads();      // #1: r(.)h visible; every wave is done reading hbuf
+
+        // candidate, h-part:  acc_c += Wc[I:,:]^T (r (.) h_{t-1})
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            const f32x4 rb = rhbuf[nn * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kc = 4 * nn + e;
+                acc_c[0] = mfma4(wch[0][kc], rb[e], acc_c[0]);
+                acc_c[1] = mfma4(wch[1][kc], rb[e], acc_c[1]);
+            }
+        }
+        const bool live = t < len_s;       // dynamic_rnn copy-through past seq_len
+        f32x4 hout[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = tanh_f(acc_c[j][e]);
+                const float hn = u[j][e] * hreg[j][e] + (1.0f - u[j][e]) * c;
+                hreg[j][e] = live ? hn : hreg[j][e];
+                hout[j][e] = live ? hn : 0.f;
+            }
+            hbuf[(2 * w + j) * 64 + lane] = hreg[j];
+            if (!LAST) {
+                const f32x4 o = hreg[j];
+                p.h_out[((size_t)group * T + t) * NT * 64 + (2 * w + j) * 64 + lane] =
+                    make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        if (LAST) {
+            // partial logits over this wave's 32 units: Wfc^T[:, units] h'[units]
+            f32x4 accf = bfc4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accf = mfma4(wfc[j][e], hout[j][e], accf);
+            if (g < 2)
+                *reinterpret_cast<f32x4*>(stage + ((w * kFlushSteps + (t & (kFlushSteps - 1))) * 16 + s) * 8 + 4 * g) = accf;
+        }
+        cand_x();             // frame t+1
+        __syncthreads();      // #2: h_t visible; every wave is done reading rhbuf
+        if (LAST && w == 0 && (((t + 1) & (kFlushSteps - 1)) == 0 || t == T - 1)) {
+            const int t0 = t & ~(kFlushSteps - 1);
+            flush_logits(p, stage, carry, group, t0, t - t0 + 1, lane, t == T - 1);
+        }
+    }
+
+    if (bvalid) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<f32x4*>(p.state_out + (size_t)b * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
+    }
+    if (LAST && T == 0 && tid < 16) { /* nothing to flush; prev_word unchanged */ }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic kernel: H = 64*TPW, weights streamed from L2 every frame (group-of-4 fragment layout).
+// Same orientation, exchange layout and epilogue; no software pipeline.
+// ------------------------------------------------------------------------------------------------
+template <int TPW, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p) {
+    constexpr int NT = 4 * TPW, H = 64 * TPW;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, g = lane >> 4, s = lane & 15;
+    const int group = blockIdx.x;
+    const int b_raw = group * kStreamsPerGroup + s;
+    const bool bvalid = b_raw < p.B;
+    const int b = bvalid ? b_raw : p.B - 1;
+    const int T = p.T, I = p.I;
+    const int KCX4 = p.KCX / 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* hbuf = reinterpret_cast<f32x4*>(smem);
+    f32x4* rhbuf = hbuf + NT * 64;
+    float* stage = reinterpret_cast<float*>(rhbuf + NT * 64);
+    int* carry = reinterpret_cast<int*>(stage + 4 * kFlushSteps * 16 * 8);
+
+    const f32x4* wx = reinterpret_cast<const f32x4*>(p.wx);   // [NT][3][KCX4][64]
+    const f32x4* wh = reinterpret_cast<const f32x4*>(p.wh);   // [NT][3][NT][64]
+
+    f32x4 bias_r[TPW], bias_u[TPW], bias_c[TPW], hreg[TPW];
+    const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
+    const int len_s = p.seq_len ? p.seq_len[b] : T;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int n = TPW * w + j;
+        bias_r[j] = ld4(p.bias + 0 * H + n * 16 + 4 * g);
+        bias_u[j] = ld4(p.bias + 1 * H + n * 16 + 4 * g);
+        bias_c[j] = ld4(p.bias + 2 * H + n * 16 + 4 * g);
+        hreg[j] = do_reset ? splat4(0.f) : ld4(p.state_in + (size_t)b * H + n * 16 + 4 * g);
+        hbuf[n * 64 + lane] = hreg[j];
+    }
+    f32x4 bfc4 = splat4(0.f);
+    if (LAST) {
+        if (w == 0) bfc4 = ld4(p.bfc + 4 * g);
+        if (tid < 16) {
+            const int bb = group * kStreamsPerGroup + tid;
+            int pw = -1;
+            if (bb < p.B && p.prev_word && !(p.reset && p.reset[bb])) pw = p.prev_word[bb];
+            carry[tid] = pw;
+        }
+    }
+    const float* xrow = FIRST ? p.x_mel + (size_t)b * T * I : nullptr;
+    const f32x4* xprev = FIRST ? nullptr
+                               : reinterpret_cast<const f32x4*>(p.x_prev) + (size_t)group * T * NT * 64 + lane;
+    const bool vec_ok = (I & 3) == 0;
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        f32x4 acc_r[TPW], acc_u[TPW], acc_c[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; acc_c[j] = bias_c[j]; }
+        // x-part (gates and candidate)
+        for (int k4 = 0; k4 < KCX4; ++k4) {
+            f32x4 xb;
+            if (FIRST) {
+                const int k = 16 * k4 + 4 * g;
+                const float* src = xrow + (size_t)t * I + k;
+                if (vec_ok && k + 3 < I) {
+                    xb = ld4(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xb[e] = (k + e < I) ? src[e] : 0.f;
+                }
+            } else {
+                xb = xprev[((size_t)t * NT + k4) * 64];
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const int n = TPW * w + j;
+                const f32x4 ar = wx[((n * 3 + 0) * KCX4 + k4) * 64 + lane];
+                const f32x4 au = wx[((n * 3 + 1) * KCX4 + k4) * 64 + lane];
+                const f32x4 ac = wx[((n * 3 + 2) * KCX4 + k4) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc_r[j] = mfma4(ar[e], xb[e], acc_r[j]);
+                    acc_u[j] = mfma4(au[e], xb[e], acc_u[j]);
+                    acc_c[j] = mfma4(ac[e], xb[e], acc_c[j]);
+                }
+            }
+        }
+        // gates, h-part
+        for (int k4 = 0; k4 < NT; ++k4) {
+            const f32x4 hb = hbuf[k4 * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const int n = TPW * w + j;
+                const f32x4 ar = wh[((n * 3 + 0) * NT + k4) * 64 + lane];
+                const f32x4 au = wh[((n * 3 + 1) * NT + k4) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc_r[j] = mfma4(ar[e], hb[e], acc_r[j]);
+                    acc_u[j] = mfma4(au[e], hb[e], acc_u[j]);
+                }
+            }
+        }
+        f32x4 u[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            f32x4 rh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rh[e] = sigmoid_f(acc_r[j][e]) * hreg[j][e];
+                u[j][e] = sigmoid_f(acc_u[j][e]);
+            }
+            rhbuf[(TPW * w + j) * 64 + lane] = rh;
+        }
+        __syncthreads();
+        for (int k4 = 0; k4 < NT; ++k4) {
+            const f32x4 rb = rhbuf[k4 * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const int n = TPW * w + j;
+                const f32x4 ac = wh[((n * 3 + 2) * NT + k4) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc_c[j] = mfma4(ac[e], rb[e], acc_c[j]);
+            }
+        }
+        const bool live = t < len_s;
+        f32x4 accf = bfc4;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int n = TPW * w + j;
+            f32x4 hout;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = tanh_f(acc_c[j][e]);
+                const float hn = u[j][e] * hreg[j][e] + (1.0f - u[j][e]) * c;
+                hreg[j][e] = live ? hn : hreg[j][e];
+                hout[e] = live ? hn : 0.f;
+            }
+            hbuf[n * 64 + lane] = hreg[j];
+            if (!LAST) {
+                const f32x4 o = hreg[j];
+                p.h_out[((size_t)group * T + t) * NT * 64 + n * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accf = mfma4(p.wfc[(n * 4 + e) * 64 + lane], hout[e], accf);
+            }
+        }
+        if (LAST && g < 2)
+            *reinterpret_cast<f32x4*>(stage + ((w * kFlushSteps + (t & (kFlushSteps - 1))) * 16 + s) * 8 + 4 * g) = accf;
+        __syncthreads();
+        if (LAST && w == 0 && (((t + 1) & (kFlushSteps - 1)) == 0 || t == T - 1)) {
+            const int t0 = t & ~(kFlushSteps - 1);
+            flush_logits(p, stage, carry, group, t0, t - t0 + 1, lane, t == T - 1);
+        }
+    }
+    if (bvalid) {
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+            *reinterpret_cast<f32x4*>(p.state_out + (size_t)b * H + (TPW * w + j) * 16 + 4 * g) = hreg[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static size_t resident_lds_bytes(int kcx, bool last) {
+    size_t n = 2 * 8 * 64 * 16 + (size_t)4 * kcx * 64 * 16;
+    if (last) n += 4 * kFlushSteps * 16 * 8 * 4 + 16 * 4;
+    return n;
+}
+static size_t generic_lds_bytes(int hidden, bool last) {
+    size_t n = (size_t)2 * (hidden / 16) * 64 * 16;
+    if (last) n += 4 * kFlushSteps * 16 * 8 * 4 + 16 * 4;
+    return n;
+}
+
+int gru_resident_kcx(int in_dim, bool first) { return first ? (in_dim + 3) / 4 : 32; }
+
+bool gru_resident_supported(int hidden, int in_dim, bool first) {
+    if (hidden != 128) return false;
+    if (!first) return in_dim == 128;
+    const int kcx = (in_dim + 3) / 4;
+    return kcx == 10 || kcx == 15;
+}
+
+template <typename K>
+static hipError_t launch_with_lds(K kernel, const GruLayerParams& p, size_t lds, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
+    hipLaunchKernelGGL(kernel, dim3(groups), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool last, hipStream_t st) {
+    const size_t lds = resident_lds_bytes(p.KCX, last);
+#define KWS_RES(KCX_, F_, L_) return launch_with_lds(gru_layer_resident<KCX_, F_, L_>, p, lds, st)
+    if (first) {
+        if (p.KCX == 10) { if (last) KWS_RES(10, true, true); else KWS_RES(10, true, false); }
+        if (p.KCX == 15) { if (last) KWS_RES(15, true, true); else KWS_RES(15, true, false); }
+        return hipErrorInvalidValue;
+    }
+    if (last) KWS_RES(32, false, true); else KWS_RES(32, false, false);
+#undef KWS_RES
+}
+
+hipError_t launch_gru_layer_generic(const GruLayerParams& p, int hidden, bool first, bool last,
+                                    hipStream_t st) {
+    const size_t lds = generic_lds_bytes(hidden, last);
+#define KWS_GEN(TPW_) \
+    do { \
+        if (first && last) return launch_with_lds(gru_layer_generic<TPW_, true, true>, p, lds, st); \
+        if (first) return launch_with_lds(gru_layer_generic<TPW_, true, false>, p, lds, st); \
+        if (last) return launch_with_lds(gru_layer_generic<TPW_, false, true>, p, lds, st); \
+        return launch_with_lds(gru_layer_generic<TPW_, false, false>, p, lds, st); \
+    } while (0)
+    if (hidden == 64) KWS_GEN(1);
+    if (hidden == 128) KWS_GEN(2);
+    if (hidden == 256) KWS_GEN(4);
+#undef KWS_GEN
+    return hipErrorInvalidValue;
+}
+
+}  // namespace kws

@@ -1,0 +1,431 @@
+// C ABI of libkws_amd.so (include/kws_amd.h): handle management, weight re-tiling, kws_step.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kws_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(e == hipErrorOutOfMemory ? KWS_ERR_OUT_OF_MEMORY : KWS_ERR_HIP, "%s: %s", what,
+                hipGetErrorString(e));
+}
+#define KWS_HIP(call)                                         \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);     \
+    } while (0)
+
+struct LayerDev {
+    int in_dim;
+    // offsets (floats) into the single device allocation
+    size_t wx_res, wh_res, wx_gen, wh_gen, bias;
+    int kcx_res, kcx_gen;
+    bool resident_ok;
+};
+
+}  // namespace
+
+struct kws_model {
+    kws_config cfg;
+    int device = 0;
+    int kernel_kind = KWS_KERNEL_AUTO;
+    std::vector<LayerDev> layers;
+    size_t wfc_off = 0, bfc_off = 0;
+    float* d_weights = nullptr;
+    float4* scratch[2] = {nullptr, nullptr};
+    size_t scratch_bytes = 0;
+    // profiling
+    bool profiling = false;
+    struct Pending { int slot; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::vector<float> ms_sum;
+    std::vector<int32_t> launches;
+};
+
+namespace {
+
+bool config_ok(const kws_config* c, int* code) {
+    if (!c) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "config is null"); return false; }
+    if (c->n_mel < 1 || c->n_mel > 1024) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "n_mel=%d out of range [1,1024]", c->n_mel); return false; }
+    if (c->num_layers < 1 || c->num_layers > 8) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "num_layers=%d out of range [1,8]", c->num_layers); return false; }
+    if (c->num_classes < 3 || c->num_classes > kws::kMaxClasses) { *code = fail(KWS_ERR_UNSUPPORTED, "num_classes=%d unsupported (3..8)", c->num_classes); return false; }
+    if (c->hidden != 64 && c->hidden != 128 && c->hidden != 256) { *code = fail(KWS_ERR_UNSUPPORTED, "hidden=%d unsupported (64, 128, 256)", c->hidden); return false; }
+    return true;
+}
+
+size_t weights_floats(const kws_config* c) {
+    size_t n = 0;
+    int in = c->n_mel;
+    const size_t H = c->hidden;
+    for (int l = 0; l < c->num_layers; ++l) {
+        n += (size_t)(in + H) * 3 * H + 3 * H;
+        in = c->hidden;
+    }
+    return n + H * c->num_classes + c->num_classes;
+}
+
+// K-index permutation of the "xl" layout: chunk kc, lane group g -> source row
+inline int kmap_grouped(int kc, int g) { return 16 * (kc / 4) + 4 * g + (kc % 4); }
+inline int kmap_interleaved(int kc, int g) { return 4 * kc + g; }
+
+// gate q of canonical layer weights: q=0 r (Wg[:, :H]), q=1 u (Wg[:, H:]), q=2 c (Wc)
+inline float wq(const float* Wg, const float* Wc, int H, int q, int row, int unit) {
+    return q == 2 ? Wc[(size_t)row * H + unit] : Wg[(size_t)row * 2 * H + q * H + unit];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* kws_version(void) { return "kws_amd 0.1 (gfx950)"; }
+const char* kws_last_error(void) { return g_last_error.c_str(); }
+
+size_t kws_weights_nbytes(const kws_config* cfg) {
+    int code;
+    if (!config_ok(cfg, &code)) return 0;
+    return weights_floats(cfg) * sizeof(float);
+}
+
+int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, kws_handle* out) {
+    int code;
+    if (!out) return fail(KWS_ERR_INVALID_ARGUMENT, "out handle pointer is null");
+    *out = nullptr;
+    if (!config_ok(cfg, &code)) return code;
+    if (!weights_blob) return fail(KWS_ERR_INVALID_ARGUMENT, "weights_blob is null");
+    const size_t need = weights_floats(cfg) * sizeof(float);
+    if (nbytes != need)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "weights_blob has %zu bytes, config needs %zu", nbytes, need);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(KWS_ERR_NO_DEVICE, "no HIP device visible");
+
+    kws_model* m = new (std::nothrow) kws_model();
+    if (!m) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
+    m->cfg = *cfg;
+    KWS_HIP(hipGetDevice(&m->device));
+    const int H = cfg->hidden, NT = H / 16, KCH = H / 4, C = cfg->num_classes;
+
+    std::vector<float> host;
+    auto reserve = [&](size_t n) { size_t off = host.size(); host.resize(off + ((n + 3) & ~size_t(3)), 0.f); return off; };
+    const float* p = static_cast<const float*>(weights_blob);
+    int in = cfg->n_mel;
+    for (int l = 0; l < cfg->num_layers; ++l) {
+        const bool first = l == 0;
+        const float* Wg = p;
+        const float* bg = Wg + (size_t)(in + H) * 2 * H;
+        const float* Wc = bg + 2 * H;
+        const float* bc = Wc + (size_t)(in + H) * H;
+        LayerDev L;
+        L.in_dim = in;
+        L.resident_ok = kws::gru_resident_supported(H, in, first);
+        L.kcx_res = kws::gru_resident_kcx(in, first);
+        L.kcx_gen = 4 * ((in + 15) / 16);
+        // biases [3][H]
+        L.bias = reserve(3 * (size_t)H);
+        for (int j = 0; j < 2 * H; ++j) host[L.bias + j] = bg[j];
+        for (int j = 0; j < H; ++j) host[L.bias + 2 * H + j] = bc[j];
+        // h-part, fragment-major [NT][3][KCH][64] (resident) and group-of-4 [NT][3][NT][64][4] (generic)
+        L.wh_res = reserve((size_t)NT * 3 * KCH * 64);
+        L.wh_gen = reserve((size_t)NT * 3 * KCH * 64);
+        for (int n = 0; n < NT; ++n)
+            for (int q = 0; q < 3; ++q)
+                for (int kc = 0; kc < KCH; ++kc)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 4, i = lane & 15;
+                        const float v = wq(Wg, Wc, H, q, in + kmap_grouped(kc, g), n * 16 + i);
+                        host[L.wh_res + (((size_t)(n * 3 + q) * KCH + kc) * 64 + lane)] = v;
+                        host[L.wh_gen + ((((size_t)(n * 3 + q) * NT + kc / 4) * 64 + lane) * 4 + kc % 4)] = v;
+                    }
+        // x-part
+        L.wx_res = reserve((size_t)NT * 3 * L.kcx_res * 64);
+        L.wx_gen = reserve((size_t)NT * 3 * L.kcx_gen * 64);
+        for (int n = 0; n < NT; ++n)
+            for (int q = 0; q < 3; ++q)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 4, i = lane & 15;
+                    for (int kc = 0; kc < L.kcx_res; ++kc) {
+                        const int row = first ? kmap_interleaved(kc, g) : kmap_grouped(kc, g);
+                        host[L.wx_res + (((size_t)(n * 3 + q) * L.kcx_res + kc) * 64 + lane)] =
+                            row < in ? wq(Wg, Wc, H, q, row, n * 16 + i) : 0.f;
+                    }
+                    for (int kc = 0; kc < L.kcx_gen; ++kc) {
+                        const int row = kmap_grouped(kc, g);
+                        host[L.wx_gen + ((((size_t)(n * 3 + q) * (L.kcx_gen / 4) + kc / 4) * 64 + lane) * 4 + kc % 4)] =
+                            row < in ? wq(Wg, Wc, H, q, row, n * 16 + i) : 0.f;
+                    }
+                }
+        m->layers.push_back(L);
+        p = bc + H;
+        in = H;
+    }
+    // dense: Wfc [H,C] -> A fragments of Wfc^T padded to 16 rows, [KCH][64]; bias padded to 16
+    const float* Wfc = p;
+    const float* bfc = Wfc + (size_t)H * C;
+    m->wfc_off = reserve((size_t)KCH * 64);
+    for (int kc = 0; kc < KCH; ++kc)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, i = lane & 15;
+            host[m->wfc_off + (size_t)kc * 64 + lane] = i < C ? Wfc[(size_t)kmap_grouped(kc, g) * C + i] : 0.f;
+        }
+    m->bfc_off = reserve(16);
+    for (int i = 0; i < C; ++i) host[m->bfc_off + i] = bfc[i];
+
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_weights), host.size() * sizeof(float));
+    if (e != hipSuccess) { delete m; return hip_fail(e, "hipMalloc(weights)"); }
+    e = hipMemcpy(m->d_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(m->d_weights); delete m; return hip_fail(e, "hipMemcpy(weights)"); }
+    m->ms_sum.assign(cfg->num_layers, 0.f);
+    m->launches.assign(cfg->num_layers, 0);
+    *out = m;
+    return KWS_OK;
+}
+
+int kws_destroy(kws_handle h) {
+    if (!h) return KWS_OK;
+    hipDeviceSynchronize();
+    for (auto& pd : h->pending) { hipEventDestroy(pd.a); hipEventDestroy(pd.b); }
+    for (auto ev : h->event_pool) hipEventDestroy(ev);
+    if (h->d_weights) hipFree(h->d_weights);
+    for (int i = 0; i < 2; ++i) if (h->scratch[i]) hipFree(h->scratch[i]);
+    delete h;
+    return KWS_OK;
+}
+
+int kws_set_kernel(kws_handle h, int kind) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (kind != KWS_KERNEL_AUTO && kind != KWS_KERNEL_GENERIC && kind != KWS_KERNEL_RESIDENT)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "unknown kernel kind %d", kind);
+    if (kind == KWS_KERNEL_RESIDENT)
+        for (const auto& L : h->layers)
+            if (!L.resident_ok)
+                return fail(KWS_ERR_UNSUPPORTED, "resident kernels need hidden=128 and n_mel in {37..40, 57..60}; got hidden=%d n_mel=%d",
+                            h->cfg.hidden, h->cfg.n_mel);
+    h->kernel_kind = kind;
+    return KWS_OK;
+}
+
+static int ensure_scratch(kws_handle h, int B, int T) {
+    if (h->cfg.num_layers < 2) return KWS_OK;
+    const size_t groups = (size_t)(B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
+    const size_t bytes = groups * (size_t)T * h->cfg.hidden * 16 * sizeof(float);
+    if (bytes <= h->scratch_bytes) return KWS_OK;
+    KWS_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 2; ++i) if (h->scratch[i]) { hipFree(h->scratch[i]); h->scratch[i] = nullptr; }
+    h->scratch_bytes = 0;
+    const int nbuf = h->cfg.num_layers > 2 ? 2 : 1;
+    for (int i = 0; i < nbuf; ++i) KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
+    h->scratch_bytes = bytes;
+    return KWS_OK;
+}
+
+int kws_reserve(kws_handle h, int B, int T) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (B < 0 || T < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative B=%d or T=%d", B, T);
+    return ensure_scratch(h, B, T);
+}
+
+int kws_set_profiling(kws_handle h, int enable) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    h->profiling = enable != 0;
+    return KWS_OK;
+}
+
+int kws_kernel_times(kws_handle h, float* ms_sum, int32_t* launches, int reset) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    for (auto& pd : h->pending) {
+        KWS_HIP(hipEventSynchronize(pd.b));
+        float ms = 0.f;
+        KWS_HIP(hipEventElapsedTime(&ms, pd.a, pd.b));
+        h->ms_sum[pd.slot] += ms;
+        h->launches[pd.slot] += 1;
+        h->event_pool.push_back(pd.a);
+        h->event_pool.push_back(pd.b);
+    }
+    h->pending.clear();
+    for (int l = 0; l < h->cfg.num_layers; ++l) {
+        if (ms_sum) ms_sum[l] = h->ms_sum[l];
+        if (launches) launches[l] = h->launches[l];
+    }
+    if (reset) {
+        std::fill(h->ms_sum.begin(), h->ms_sum.end(), 0.f);
+        std::fill(h->launches.begin(), h->launches.end(), 0);
+    }
+    return KWS_OK;
+}
+
+int kws_step(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
+             float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
+             int32_t* prev_word, float decode2_thres, int B, int T, void* stream) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (B < 0 || T < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative B=%d or T=%d", B, T);
+    if (!state_in || !state_out) return fail(KWS_ERR_INVALID_ARGUMENT, "state_in/state_out must not be null");
+    if (tokens && !prev_word) return fail(KWS_ERR_INVALID_ARGUMENT, "tokens requires prev_word");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const kws_config& c = h->cfg;
+    const int H = c.hidden, L = c.num_layers;
+    if (B == 0) return KWS_OK;
+    if (T == 0) {
+        if (state_out != state_in)
+            KWS_HIP(hipMemcpyAsync(state_out, state_in, (size_t)L * B * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return KWS_OK;
+    }
+    if (!mel) return fail(KWS_ERR_INVALID_ARGUMENT, "mel is null");
+    int rc = ensure_scratch(h, B, T);
+    if (rc != KWS_OK) return rc;
+
+    for (int l = 0; l < L; ++l) {
+        const LayerDev& Ld = h->layers[l];
+        const bool first = l == 0, last = l == L - 1;
+        const bool resident = h->kernel_kind == KWS_KERNEL_RESIDENT ||
+                              (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok);
+        kws::GruLayerParams p;
+        memset(&p, 0, sizeof(p));
+        p.wx = h->d_weights + (resident ? Ld.wx_res : Ld.wx_gen);
+        p.wh = h->d_weights + (resident ? Ld.wh_res : Ld.wh_gen);
+        p.bias = h->d_weights + Ld.bias;
+        p.wfc = h->d_weights + h->wfc_off;
+        p.bfc = h->d_weights + h->bfc_off;
+        p.x_mel = mel;
+        p.x_prev = first ? nullptr : h->scratch[(l - 1) & 1];
+        p.h_out = last ? nullptr : h->scratch[l & 1];
+        p.state_in = state_in + (size_t)l * B * H;
+        p.state_out = state_out + (size_t)l * B * H;
+        p.seq_len = seq_len;
+        p.reset = reset_mask;
+        p.logits = logits;
+        p.softmax = softmax;
+        p.tokens = tokens;
+        p.prev_word = prev_word;
+        p.decode_thres = decode2_thres;
+        p.value_clip = c.value_clip;
+        p.use_relu = c.use_relu;
+        p.B = B; p.T = T; p.I = Ld.in_dim; p.C = c.num_classes;
+        p.KCX = resident ? Ld.kcx_res : Ld.kcx_gen;
+
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (h->profiling) {
+            for (hipEvent_t* ev : {&ea, &eb}) {
+                if (!h->event_pool.empty()) { *ev = h->event_pool.back(); h->event_pool.pop_back(); }
+                else KWS_HIP(hipEventCreate(ev));
+            }
+            KWS_HIP(hipEventRecord(ea, st));
+        }
+        hipError_t e = resident ? kws::launch_gru_layer_resident(p, first, last, st)
+                                : kws::launch_gru_layer_generic(p, H, first, last, st);
+        if (e != hipSuccess) return hip_fail(e, resident ? "launch gru_layer_resident" : "launch gru_layer_generic");
+        if (h->profiling) {
+            KWS_HIP(hipEventRecord(eb, st));
+            h->pending.push_back({l, ea, eb});
+        }
+    }
+    return KWS_OK;
+}
+
+int kws_ctc_decode(int kind, const float* softmax, const int32_t* lengths, int B, int T, int C, int lockout,
+                   float thres, float loose_thres, int32_t* words, int32_t* counts, int max_words, void* stream) {
+    if (kind != KWS_DECODE && kind != KWS_DECODE2 && kind != KWS_DECODE_STRICT)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "unknown decode kind %d", kind);
+    if (B < 0 || T < 0 || max_words < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative dimension");
+    if (C < 3 || C > 64) return fail(KWS_ERR_INVALID_ARGUMENT, "classnum=%d out of range [3,64]", C);
+    if (kind == KWS_DECODE && C < 5) return fail(KWS_ERR_INVALID_ARGUMENT, "ctc_decode slices columns 1:5 and needs classnum >= 5, got %d", C);
+    if (lockout < 1 && kind != KWS_DECODE2) return fail(KWS_ERR_INVALID_ARGUMENT, "lockout must be >= 1, got %d", lockout);
+    if (B == 0) return KWS_OK;
+    if (!counts || (!words && max_words > 0) || (!softmax && T > 0))
+        return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    hipError_t e = kws::launch_ctc_decode(kind, softmax, lengths, B, T, C, lockout, thres, loose_thres, words,
+                                          counts, max_words, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch ctc_decode");
+    return KWS_OK;
+}
+
+int kws_ctc_predict(const int32_t* words, const int32_t* counts, int B, int max_words, const char* label,
+                    int32_t* hit, void* stream) {
+    if (!label) return fail(KWS_ERR_INVALID_ARGUMENT, "label is null");
+    const int n = (int)strlen(label);
+    if (n > 16) return fail(KWS_ERR_INVALID_ARGUMENT, "label longer than 16 digits");
+    int32_t digits[16] = {0};
+    for (int i = 0; i < n; ++i) {
+        if (label[i] < '1' || label[i] > '9') return fail(KWS_ERR_INVALID_ARGUMENT, "label must be digits 1..9, got '%s'", label);
+        digits[i] = label[i] - '0';
+    }
+    if (B < 0 || max_words < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative dimension");
+    if (B == 0) return KWS_OK;
+    if (!counts || !hit || (!words && max_words > 0)) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // digits travel by value inside the launcher (kernel argument), no device allocation
+    hipError_t e = kws::launch_ctc_predict(words, counts, B, max_words, digits, n, hit, st);
+    if (e != hipSuccess) return hip_fail(e, "launch ctc_predict");
+    return KWS_OK;
+}
+
+int kws_vad(const float* pcm, int B, int N, float thres, uint8_t* speech, float* abs_sum, void* stream) {
+    if (B < 0 || N < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative dimension");
+    if (B == 0) return KWS_OK;
+    if (!speech || (!pcm && N > 0)) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    hipError_t e = kws::launch_vad(pcm, B, N, thres, speech, abs_sum, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch vad");
+    return KWS_OK;
+}
+
+int kws_octbit_matmul(const float* x, const int8_t* Wq, float scale_w, const float* bias, float* out, int A,
+                      int K, int N, int per_row_scale, void* stream) {
+    // preconditions of octbit/octbit_mat_mul_op.cc:41-46,61-73 as error codes
+    if (!(scale_w > 0.f)) return fail(KWS_ERR_INVALID_ARGUMENT, "scale has to be positive");
+    if (A < 0 || K < 0 || N < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative dimension");
+    if (K % 64 != 0) return fail(KWS_ERR_INVALID_ARGUMENT, "K=%d must be a multiple of 64", K);
+    if (A == 0 || N == 0) return KWS_OK;
+    if (K == 0) return fail(KWS_ERR_INVALID_ARGUMENT, "K must be positive");
+    if (!x || !Wq || !bias || !out) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* ws = nullptr;
+    KWS_HIP(hipMallocAsync(reinterpret_cast<void**>(&ws), (size_t)(2 * A + 2) * sizeof(float), st));
+    hipError_t e = kws::launch_octbit_matmul(x, Wq, scale_w, bias, out, A, K, N, per_row_scale, ws, st);
+    hipError_t e2 = hipFreeAsync(ws, st);
+    if (e != hipSuccess) return hip_fail(e, "launch octbit_matmul");
+    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync");
+    return KWS_OK;
+}
+
+int kws_octbit_quantize(const float* W, int K, int N, int8_t* Wq, float* scale, float* bias) {
+    if (!W || !Wq || !scale || !bias) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (K <= 0 || N <= 0) return fail(KWS_ERR_INVALID_ARGUMENT, "K and N must be positive");
+    // octbit/octbit_graph.py:196-204: scale = max|W|/127 in double, np.round = half-to-even
+    float mx = W[0], mn = W[0];
+    for (size_t i = 0; i < (size_t)K * N; ++i) { mx = std::max(mx, W[i]); mn = std::min(mn, W[i]); }
+    const double nmax = std::max(std::fabs((double)mx), std::fabs((double)mn));
+    if (!(nmax > 0.0)) return fail(KWS_ERR_INVALID_ARGUMENT, "weight matrix is all zero: scale would be 0");
+    // numpy: float32 array / python float -> float32 array divided by a float32-cast scalar
+    const float sc32 = (float)(nmax / 127.0);
+    for (int j = 0; j < N; ++j) bias[j] = 0.f;
+    std::vector<double> b(N, 0.0);
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < N; ++j) {
+            const float qf = std::nearbyintf(W[(size_t)i * N + j] / sc32);
+            Wq[(size_t)j * K + i] = (int8_t)qf;
+            b[j] += (double)qf * 127.0;
+        }
+    for (int j = 0; j < N; ++j) bias[j] = (float)b[j];
+    *scale = (float)(nmax / 127.0);
+    return KWS_OK;
+}
+
+}  // extern "C"

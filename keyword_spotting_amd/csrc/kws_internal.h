@@ -1,0 +1,68 @@
+// Internal declarations shared by the HIP translation units of libkws_amd.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kws_amd.h"
+
+namespace kws {
+
+constexpr int kStreamsPerGroup = 16;  // MFMA N dimension: one workgroup advances 16 streams
+constexpr int kFlushSteps = 4;        // logits are staged in LDS and flushed every 4 frames
+constexpr int kMaxClasses = 8;
+
+// One launch = one GRU layer over all T frames of the call, for every 16-stream group.
+//
+// Exchange layout ("xl"): a [H x 16 streams] activation block is stored as [H/16][64 lanes] float4,
+// lane = 16*g + s, component r  <->  unit 16*n + 4*g + r of stream s.  This is at once the MFMA
+// 16x16x4 C/D register image of tile n and, read back as float4, the B operand of the four
+// k-chunks 4n..4n+3 -- so hidden state never needs a cross-lane transpose.
+struct GruLayerParams {
+    // weights (device, packed by pack.cpp)
+    const float* wx;        // x-part fragments  resident: [NT][3][KCX][64]   generic: [NT][3][KCX4][64][4]
+    const float* wh;        // h-part fragments  resident: [NT][3][KCH][64]   generic: [NT][3][NT][64][4]
+    const float* bias;      // [3][H]  (r, u, c)
+    const float* wfc;       // LAST: [H/4][64] fragments of Wfc^T padded to 16 rows
+    const float* bfc;       // LAST: [16] padded
+    // activations
+    const float* x_mel;     // FIRST: mel [B,T,I]
+    const float4* x_prev;   // !FIRST: previous layer's output, xl layout [G][T][NT][64]
+    float4* h_out;          // !LAST: this layer's output, xl layout
+    const float* state_in;  // [B,H] of this layer
+    float* state_out;       // [B,H]
+    const int32_t* seq_len; // [B] or null
+    const uint8_t* reset;   // [B] or null
+    // LAST-layer epilogue
+    float* logits;          // [B,T,C] or null
+    float* softmax;         // [B,T,C] or null
+    int8_t* tokens;         // [B,T] or null
+    int32_t* prev_word;     // [B] or null
+    float decode_thres;
+    float value_clip;
+    int use_relu;
+    int B, T, I, C;
+    int KCX;                // x-part k-chunks (generic: multiple of 4)
+};
+
+// launchers (gru_kernels.hip)
+bool gru_resident_supported(int hidden, int in_dim, bool first);
+int gru_resident_kcx(int in_dim, bool first);
+hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool last, hipStream_t st);
+hipError_t launch_gru_layer_generic(const GruLayerParams& p, int hidden, bool first, bool last,
+                                    hipStream_t st);
+
+// decode_kernels.hip
+hipError_t launch_ctc_decode(int kind, const float* softmax, const int32_t* lengths, int B, int T, int C,
+                             int lockout, float thres, float loose_thres, int32_t* words,
+                             int32_t* counts, int max_words, hipStream_t st);
+hipError_t launch_ctc_predict(const int32_t* words, const int32_t* counts, int B, int max_words,
+                              const int32_t* label_digits, int label_len, int32_t* hit, hipStream_t st);
+hipError_t launch_vad(const float* pcm, int B, int N, float thres, uint8_t* speech, float* abs_sum,
+                      hipStream_t st);
+
+// octbit_kernels.hip
+hipError_t launch_octbit_matmul(const float* x, const int8_t* Wq, float scale_w, const float* bias,
+                                float* out, int A, int K, int N, int per_row, float* range_ws,
+                                hipStream_t st);
+
+}  // namespace kws

@@ -1,0 +1,175 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (numpy) of the reference's streaming GRU path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product (keyword_spotting_amd/) never imports anything under oracle/.
+
+PARITY UNPINNED for this file: the reference's GRU / dense / softmax arithmetic lives in
+TensorFlow 1.x (`tensorflow.contrib.rnn.GRUCell`, `MultiRNNCell`, `dynamic_rnn`), a third-party
+dependency that is neither vendored in /root/reference nor version-pinned (no requirements file;
+era: TF 1.1 - 1.3, see utils/stft.py:26, models/rnn_ctc.py:182) and cannot be installed here.
+The reference holds no test or golden vector for this stage.  This module therefore restates the
+published TF-1.x GRUCell algorithm and is anchored on the reference's own call sites:
+
+  models/rnn_ctc.py:179-199  get_cell      -> plain GRUCell(num_units=H, activation=tanh)
+  models/rnn_ctc.py:202-244  inference1    -> MultiRNNCell + dynamic_rnn, batch-major, initial_state tuple
+  models/rnn_ctc.py:247-284  inference2    -> logits = flat(h) @ W[H,C] + b (+ optional relu / clip[0,20])
+  models/rnn_ctc.py:156-165  DeployModel   -> unstack state, stack state, logit, softmax
+
+TF-1.x GRUCell.call (restated):
+  g    = sigmoid([x, h] @ Wg + bg)          Wg:[I+H, 2H]  bg:[2H] (initialised to 1.0)
+  r, u = split(g, 2, axis=1)                r first
+  c    = tanh([x, r*h] @ Wc + bc)           Wc:[I+H, H]   bc:[H]
+  h'   = u*h + (1-u)*c                      output == new state
+TF dynamic_rnn with sequence_length: for t >= seq_len[b] the emitted output row is zero and the
+whole state tuple of row b is copied through unchanged.
+
+Three independent formulations live here and are cross-checked by tests/test_oracle_gru.py:
+  * gru_forward(dtype=float32|float64)     -- concatenated-matmul form (as TF writes it)
+  * gru_forward_split                      -- split-weight form (x-part / h-part summed separately)
+  * oracle/torch_eager.py                  -- op-by-op torch CPU form (also the "TF-CPU stand-in" timing)
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------
+# weights: canonical layout == TF variable layout
+#   per layer l: Wg [I_l+H, 2H], bg [2H], Wc [I_l+H, H], bc [H]   (I_0 = n_mel, I_l = H)
+#   Wfc [H, C], bfc [C]
+# --------------------------------------------------------------------------------------
+def init_weights(n_mel=40, hidden=128, num_layers=2, num_classes=6, seed=0):
+    """SURVEY.md 8(d) config-1 initialisation: glorot-uniform kernels (TF default for GRUCell's
+    _linear), gate bias 1.0, candidate bias 0 (TF GRUCell), fc ~ truncated N(0,1) at 2 sigma
+    (models/rnn_ctc.py:265-268), fc bias 0 (:271-273)."""
+    rng = np.random.default_rng(seed)
+    layers = []
+    for l in range(num_layers):
+        i_l = n_mel if l == 0 else hidden
+        k = i_l + hidden
+        a = np.sqrt(6.0 / (k + 2 * hidden))
+        wg = rng.uniform(-a, a, size=(k, 2 * hidden)).astype(np.float32)
+        a = np.sqrt(6.0 / (k + hidden))
+        wc = rng.uniform(-a, a, size=(k, hidden)).astype(np.float32)
+        layers.append(dict(Wg=wg, bg=np.ones(2 * hidden, np.float32),
+                           Wc=wc, bc=np.zeros(hidden, np.float32)))
+    wfc = rng.standard_normal((hidden, num_classes))
+    bad = np.abs(wfc) > 2.0
+    while bad.any():
+        wfc[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(wfc) > 2.0
+    return dict(layers=layers, Wfc=wfc.astype(np.float32),
+                bfc=np.zeros(num_classes, np.float32))
+
+
+def random_weights(n_mel, hidden, num_layers, num_classes, seed):
+    """Fully random variant (non-trivial biases) so tests exercise every term."""
+    rng = np.random.default_rng(seed)
+    w = init_weights(n_mel, hidden, num_layers, num_classes, seed)
+    for lay in w["layers"]:
+        lay["bg"] = (1.0 + 0.3 * rng.standard_normal(2 * hidden)).astype(np.float32)
+        lay["bc"] = (0.3 * rng.standard_normal(hidden)).astype(np.float32)
+    w["bfc"] = (0.5 * rng.standard_normal(num_classes)).astype(np.float32)
+    return w
+
+
+def weights_to_blob(w):
+    """Flat fp32 blob in canonical order (the C-ABI's weights_blob)."""
+    parts = []
+    for lay in w["layers"]:
+        parts += [lay["Wg"].ravel(), lay["bg"].ravel(), lay["Wc"].ravel(), lay["bc"].ravel()]
+    parts += [w["Wfc"].ravel(), w["bfc"].ravel()]
+    return np.ascontiguousarray(np.concatenate(parts).astype(np.float32))
+
+
+def synthetic_mel(batch, frames, n_mel=40, seed=1):
+    """|N(0,1)|*2, non-negative like a magnitude mel."""
+    rng = np.random.default_rng(seed)
+    return (np.abs(rng.standard_normal((batch, frames, n_mel))) * 2.0).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def gru_cell(x, h, lay, dtype):
+    """One TF-1.x GRUCell step, concatenated form.  x:[B,I] h:[B,H]."""
+    hdim = h.shape[1]
+    wg, bg = lay["Wg"].astype(dtype), lay["bg"].astype(dtype)
+    wc, bc = lay["Wc"].astype(dtype), lay["bc"].astype(dtype)
+    g = _sigmoid(np.concatenate([x, h], axis=1) @ wg + bg)
+    r, u = g[:, :hdim], g[:, hdim:]
+    c = np.tanh(np.concatenate([x, r * h], axis=1) @ wc + bc)
+    return (u * h + (1.0 - u) * c).astype(dtype)
+
+
+def gru_cell_split(x, h, lay, dtype):
+    """Same cell, split-weight form: rows [0,I) of W multiply x, rows [I,I+H) multiply h."""
+    i_l = x.shape[1]
+    hdim = h.shape[1]
+    wg, wc = lay["Wg"].astype(dtype), lay["Wc"].astype(dtype)
+    g = _sigmoid(x @ wg[:i_l] + h @ wg[i_l:] + lay["bg"].astype(dtype))
+    r, u = g[:, :hdim], g[:, hdim:]
+    c = np.tanh(x @ wc[:i_l] + (r * h) @ wc[i_l:] + lay["bc"].astype(dtype))
+    return (u * h + (1.0 - u) * c).astype(dtype)
+
+
+def _forward(cell, w, mel, state, seq_len, dtype, use_relu, value_clip):
+    mel = np.asarray(mel, dtype=dtype)
+    b, t_len, _ = mel.shape
+    nl = len(w["layers"])
+    hdim = w["Wfc"].shape[0]
+    if state is None:
+        state = np.zeros((nl, b, hdim), dtype)
+    h = [np.array(state[l], dtype=dtype) for l in range(nl)]
+    if seq_len is None:
+        seq_len = np.full(b, t_len, np.int64)
+    seq_len = np.asarray(seq_len)
+    top = np.zeros((b, t_len, hdim), dtype)
+    for t in range(t_len):
+        live = (t < seq_len)[:, None]
+        x = mel[:, t, :]
+        new_h = []
+        for l in range(nl):
+            hn = cell(x, h[l], w["layers"][l], dtype)
+            new_h.append(hn)
+            x = hn
+        # dynamic_rnn copy-through: finished rows keep every layer's state, emit zero output
+        for l in range(nl):
+            h[l] = np.where(live, new_h[l], h[l])
+        top[:, t, :] = np.where(live, new_h[-1], 0.0)
+    logits = top.reshape(-1, hdim) @ w["Wfc"].astype(dtype) + w["bfc"].astype(dtype)
+    logits = logits.reshape(b, t_len, w["Wfc"].shape[1])
+    if use_relu:                      # models/rnn_ctc.py:280-283
+        logits = np.maximum(logits, 0.0)
+        if value_clip > 0:
+            logits = np.clip(logits, 0.0, 20.0)
+    return logits.astype(dtype), np.stack(h).astype(dtype)
+
+
+def gru_forward(w, mel, state=None, seq_len=None, dtype=np.float32, use_relu=False, value_clip=-1.0):
+    """(mel[B,T,I], state[L,B,H]) -> (logits[B,T,C], state'[L,B,H]); models/rnn_ctc.py:155-163."""
+    return _forward(gru_cell, w, mel, state, seq_len, dtype, use_relu, value_clip)
+
+
+def gru_forward_split(w, mel, state=None, seq_len=None, dtype=np.float32):
+    return _forward(gru_cell_split, w, mel, state, seq_len, dtype, False, -1.0)
+
+
+def softmax(logits):
+    """models/rnn_ctc.py:165 -- softmax over the class axis."""
+    z = logits - logits.max(axis=-1, keepdims=True)
+    e = np.exp(z)
+    return (e / e.sum(axis=-1, keepdims=True)).astype(logits.dtype)
+
+
+def stream_chunks(w, mel, chunk_lens, dtype=np.float32):
+    """detector.py:190-196 / :280-285 -- feed consecutive chunks, round-trip the state."""
+    b = mel.shape[0]
+    nl, hdim = len(w["layers"]), w["Wfc"].shape[0]
+    state = np.zeros((nl, b, hdim), dtype)
+    outs, pos = [], 0
+    for n in chunk_lens:
+        lg, state = gru_forward(w, mel[:, pos:pos + n], state, dtype=dtype)
+        outs.append(lg)
+        pos += n
+    return np.concatenate(outs, axis=1), state

@@ -1,0 +1,85 @@
+"""Octbit oracle pinned by the reference's own known-answer tests (octbit/octbit_ops_test.py)."""
+import numpy as np
+
+from oracle import octbit_oracle as O
+
+
+def _kat1():
+    return (-np.ones((1, 64), np.float32), np.arange(64, dtype=np.int8)[None], 3.0,
+            np.array([127 * 2016.0], np.float32), np.array([[-6048.0]], np.float32))
+
+
+def _kat2():
+    w = np.stack([np.ones(64, np.int8)] + [np.arange(64, dtype=np.int8)] * 3)
+    bias = np.array([127 * 64.0, 127 * 2016.0, 127 * 2016.0, 127 * 2016.0], np.float32)
+    return (-np.ones((2, 64), np.float32), w, 2.0, bias,
+            np.array([[-128.0, -4032.0, -4032.0, -4032.0]] * 2, np.float32))
+
+
+def test_reference_known_answers(oracle_c):
+    for x, w, scale, bias, want in (_kat1(), _kat2()):       # octbit_ops_test.py:24-34, :41-53
+        rc, got = oracle_c.octbit_matmul(x, w, scale, bias)
+        assert rc == 0
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(O.octbit_matmul_ref(x, w, scale, bias), want)
+
+
+def test_preconditions(oracle_c):
+    x, w, scale, bias, _ = _kat1()
+    assert oracle_c.octbit_matmul(x, w, 0.0, bias)[0] == -1                       # :46 scale > 0
+    assert oracle_c.octbit_matmul(x[:, :32], w[:, :32], scale, bias)[0] == -1     # :65-67 K % 64
+
+
+def test_c_and_numpy_restatements_agree_incl_saturation_and_ties(oracle_c):
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        a, k, n = 3, 128, 9
+        x = rng.standard_normal((a, k)).astype(np.float32) * 3
+        if trial == 1:
+            x = np.abs(x)                              # unsigned branch :115-124
+        if trial == 2:
+            x[:] = 5.0
+            x[0, 0] = -5.0                             # u8 = 254 everywhere: 254*127*2 > 32767 saturates
+        if trial == 3:
+            x = (rng.integers(-254, 255, (a, k)) * 0.5).astype(np.float32)   # exact .5 quotients
+            x[0, 0], x[0, 1] = 127.0, -127.0
+        wq = rng.integers(-127, 128, (n, k)).astype(np.int8)
+        if trial == 2:
+            wq[:] = 127
+        bias = (127.0 * wq.astype(np.float64).sum(1)).astype(np.float32)
+        rc, got = oracle_c.octbit_matmul(x, wq, 0.01, bias)
+        assert rc == 0
+        np.testing.assert_array_equal(got, O.octbit_matmul_ref(x, wq, 0.01, bias))
+
+
+def test_quantiser_identities():
+    rng = np.random.default_rng(12)
+    w = rng.standard_normal((256, 40)).astype(np.float32)
+    wq, scale, bias = O.octize_weight_int8_signed(w)
+    assert wq.shape == (40, 256) and wq.dtype == np.int8
+    assert np.abs(wq).max() == 127
+    np.testing.assert_array_equal(bias, 127.0 * wq.astype(np.float64).sum(axis=1))   # octbit_graph.py:202-204
+    np.testing.assert_allclose(wq.T * scale, w, atol=scale * 0.5 + 1e-7)
+    # half-to-even (np.round), not half-away: 2.5*scale -> 2
+    w2 = np.array([[127.0, 2.5, 3.5, -2.5]], np.float32).T
+    wq2, s2, _ = O.octize_weight_int8_signed(w2)
+    assert s2 == 1.0 and wq2.ravel().tolist() == [127, 2, 4, -2]
+
+
+def test_name_rule():
+    f = O.default_octbit_matmul_name_check                     # octbit_graph.py:218-225
+    assert f("model/drnn/multi_rnn_cell/cell_1/gru_cell/gates/MatMul")
+    assert not f("model/drnn/multi_rnn_cell/cell_0/gru_cell/gates/MatMul")
+    assert not f("model/linear/linear/MatMul")
+    assert f("model/MatMul") and not f("model/mel")
+
+
+def test_quantised_matmul_tracks_float(oracle_c):
+    rng = np.random.default_rng(13)
+    w = rng.standard_normal((256, 128)).astype(np.float32) * 0.1
+    x = rng.standard_normal((1, 256)).astype(np.float32)
+    wq, scale, bias = O.octize_weight_int8_signed(w)
+    rc, got = oracle_c.octbit_matmul(x, wq, scale, bias.astype(np.float32))
+    assert rc == 0
+    ref = x @ w
+    assert np.abs(got - ref).max() < 0.05 * np.abs(ref).max()
