@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/s of the streaming GRU keyword-spotting path on N MI355X GPUs.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one kws_step call: B=4096 concurrent streams per GPU advanced by T=300 mel frames
+(BASELINE.json configs[1]: 2xGRU h=128, n_mel=40, 6 classes, fp32), state carried on the device from
+step to step, logits + softmax + fused ctc_decode2 token events written.  Inputs are resident in HBM
+before the timed region.  Weak scaling: every rank owns its own 4096 streams, no data-path collective.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_FRAME = {"total": 327168, "layer": [2 * 64512, 2 * (98304 + 768)]}   # SURVEY 8d / BASELINE.md 4
+BYTES_PER_FRAME = 160 + 24 + 24 + 1                                          # mel in, logits, softmax, token out
+PEAK_FP32_TFLOPS = 157.3                                                      # MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, w, seconds_budget=8.0):
+    """The oracle timed on this host (reference TF-1.x is not executable here or on the GPU box):
+    (ii) tight C restatement, 1 core and all cores; (i) torch-CPU eager op-by-op = 'TF-CPU stand-in'.
+    Workload = BASELINE config 1: batch 1, 300 frames, state round trip, greedy decode."""
+    import numpy as np
+    import torch
+    from oracle import build as obuild
+    from oracle import gru_oracle as G
+    from oracle import torch_eager as TE
+    out = os.path.join(ROOT, "oracle", "_build", "libkws_oracle_native.so")
+    try:
+        orc = obuild.load(native=True, out=out)
+    except Exception:
+        orc = obuild.load()
+    blob = G.weights_to_blob(w)
+    ctuple = (cfg.n_mel, cfg.hidden_size, cfg.num_layers, cfg.num_classes, 0, -1.0)
+    cores = os.cpu_count() or 1
+    mel1 = G.synthetic_mel(1, 300, cfg.n_mel, seed=1)
+    st1 = np.zeros((cfg.num_layers, 1, cfg.hidden_size), np.float32)
+
+    def run_c(mel, st, threads):
+        lg, sm, s2 = orc.gru_forward(ctuple, blob, mel, st, threads=threads)
+        for b in range(mel.shape[0]):
+            orc.ctc_decode2(sm[b], cfg.num_classes)
+        return s2
+
+    run_c(mel1, st1, 1)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_budget / 4:
+        run_c(mel1, st1, 1)
+        n += 1
+    c1 = n * 300 / (time.perf_counter() - t0)
+    meln = G.synthetic_mel(cores * 4, 300, cfg.n_mel, seed=2)
+    stn = np.zeros((cfg.num_layers, cores * 4, cfg.hidden_size), np.float32)
+    run_c(meln, stn, cores)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds_budget / 4:
+        run_c(meln, stn, cores)
+        n += 1
+    call = n * meln.shape[0] * 300 / (time.perf_counter() - t0)
+    # torch eager, op by op, batch 1, 22-frame chunks with the state round-tripping through numpy
+    torch.set_num_threads(1)
+    tw = TE.to_torch(w)
+    melt = torch.from_numpy(mel1)
+    frames, t0 = 0, time.perf_counter()
+    state = torch.zeros(cfg.num_layers, 1, cfg.hidden_size)
+    while time.perf_counter() - t0 < seconds_budget / 2:
+        for pos in range(0, 300, 22):
+            lg, sm, state = TE.gru_forward(tw, melt[:, pos:pos + 22], state)
+            state = torch.from_numpy(state.numpy().copy())
+            frames += lg.shape[1]
+    eager = frames / (time.perf_counter() - t0)
+    return {"value": call, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle/kws_oracle.c (restatement of reference semantics; TF-1.x not executable): "
+                      "%d independent batch-1 streams x 300 frames + ctc_decode2, OpenMP over %d cores, ~%.0fs"
+                      % (meln.shape[0], cores, seconds_budget / 4),
+            "single_core_value": c1,
+            "eager_stand_in": {"value": eager, "cores": 1, "what": "torch-CPU op-by-op GRUCell loop, batch 1, 22-frame "
+                               "chunks, state round trip (analogue of the reference's per-op TF dispatch)"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="streams per GPU")
+    ap.add_argument("--frames", type=int, default=300, help="mel frames per stream per step")
+    ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from keyword_spotting_amd import get_config, sharding, weights
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+
+    rank, local_rank, world = sharding.env_rank_world()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    cfg = get_config()
+    w = weights.init_weights(cfg, seed=0)
+    model = DeployModel(cfg, w, device=device, kernel=args.kernel)
+    B, T = args.batch, args.frames
+    model.reserve(B, T)
+    gen = torch.Generator(device=device).manual_seed(sharding.shard_seed(1, rank))
+    mel = (torch.randn(B, T, cfg.n_mel, generator=gen, device=device).abs() * 2).contiguous()
+    state = model.zero_state(B)
+    prev_word = model.fresh_prev_word(B)
+    out = {"logits": torch.empty(B, T, cfg.num_classes, device=device),
+           "softmax": torch.empty(B, T, cfg.num_classes, device=device),
+           "tokens": torch.empty(B, T, dtype=torch.int8, device=device)}
+
+    def step():
+        model.forward(mel, state, prev_word=prev_word, state_out=state, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    model.set_profiling(True)
+    model.kernel_times(reset=True)
+    sharding.barrier(dist, device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    sharding.barrier(dist, device)
+    elapsed = time.perf_counter() - t0
+    ktimes = model.kernel_times(reset=True)
+    model.set_profiling(False)
+    frames, seconds = sharding.reduce_throughput(dist, B * T * args.steps, elapsed, device)
+
+    if rank == 0:
+        value = frames / seconds
+        dom = max(range(len(ktimes)), key=lambda l: ktimes[l][0])
+        dom_ms = ktimes[dom][0] / max(ktimes[dom][1], 1)
+        achieved = FLOP_PER_FRAME["layer"][dom] * B * T / (dom_ms * 1e-3) / 1e12
+        all_ms = sum(k[0] / max(k[1], 1) for k in ktimes)
+        line = {
+            "metric": "mel-frames/s (real-time 10 ms-hop audio streams sustained = value/100)",
+            "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 2xGRU h=128 n_mel=40 6-class, %d concurrent streams/GPU x %d frames "
+                                   "per step, fp32, state carried on device, logits+softmax+fused ctc_decode2" % (B, T),
+                       "streams_per_gpu": B, "frames_per_step": T, "parallelism": "utterance-dp%d" % world,
+                       "kernel": model.kernel},
+            "realtime_streams": value / 100.0,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "gru_layer_%s layer %d" % ("resident" if model.kernel != "generic" else "generic", dom),
+                         "kernel_ms": dom_ms, "launches": ktimes[dom][1],
+                         "all_layers_tflops": FLOP_PER_FRAME["total"] * B * T / (all_ms * 1e-3) / 1e12,
+                         "per_layer_ms": [k[0] / max(k[1], 1) for k in ktimes],
+                         "hbm_algorithmic_GBps": BYTES_PER_FRAME * B * T / (all_ms * 1e-3) / 1e9,
+                         "hbm_frac_of_peak": BYTES_PER_FRAME * B * T / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, w)
+            line["speedup_vs_cpu_all_cores"] = value / line["cpu_baseline"]["value"]
+            line["speedup_vs_eager_stand_in_x_cores"] = value / (line["cpu_baseline"]["eager_stand_in"]["value"]
+                                                                 * line["cpu_baseline"]["cores"])
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing -- build it with `make -C keyword_spotting_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime of this process BEFORE
+        # libkws_amd.so resolves its libamdhip64 dependency, or the two would not share devices,
+        # streams and allocations (a second runtime instance sees "no HIP device").
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

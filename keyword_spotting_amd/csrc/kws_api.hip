@@ -277,12 +277,12 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
              int32_t* prev_word, float decode2_thres, int B, int T, void* stream) {
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
     if (B < 0 || T < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative B=%d or T=%d", B, T);
+    if (B == 0) return KWS_OK;   // nothing to advance (empty tensors have null data pointers)
     if (!state_in || !state_out) return fail(KWS_ERR_INVALID_ARGUMENT, "state_in/state_out must not be null");
     if (tokens && !prev_word) return fail(KWS_ERR_INVALID_ARGUMENT, "tokens requires prev_word");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const kws_config& c = h->cfg;
     const int H = c.hidden, L = c.num_layers;
-    if (B == 0) return KWS_OK;
     if (T == 0) {
         if (state_out != state_in)
             KWS_HIP(hipMemcpyAsync(state_out, state_in, (size_t)L * B * H * sizeof(float), hipMemcpyDeviceToDevice, st));

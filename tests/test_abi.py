@@ -1,0 +1,97 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/kws_amd.h declares,
+its host-side entry points validate arguments, and it fails loudly (not silently) without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, have_gpu
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "kws_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kws_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from keyword_spotting_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for sym in declared:
+        assert hasattr(lib, sym), "libkws_amd.so does not export %s" % sym
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared        # the ctypes binding covers the whole header
+
+
+def test_weights_nbytes_and_config_validation():
+    from keyword_spotting_amd import _lib
+    lib = _lib.load()
+    assert lib.kws_weights_nbytes(ctypes.byref(_lib.KwsConfig(40, 128, 2, 6, 0, -1.0))) == 657432
+    assert lib.kws_weights_nbytes(ctypes.byref(_lib.KwsConfig(60, 256, 4, 6, 0, -1.0))) == \
+        4 * ((60 + 256) * 768 + 768 + 3 * (512 * 768 + 768) + 256 * 6 + 6)
+    assert lib.kws_weights_nbytes(ctypes.byref(_lib.KwsConfig(40, 100, 2, 6, 0, -1.0))) == 0
+    assert b"hidden=100" in lib.kws_last_error()
+    assert lib.kws_weights_nbytes(ctypes.byref(_lib.KwsConfig(40, 128, 0, 6, 0, -1.0))) == 0
+    assert lib.kws_weights_nbytes(None) == 0
+
+
+def test_null_handle_and_bad_arguments_return_codes():
+    from keyword_spotting_amd import _lib
+    lib = _lib.load()
+    assert lib.kws_step(None, None, None, None, None, None, None, None, None, None, 0.4, 1, 1, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_set_kernel(None, 0) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_destroy(None) == _lib.KWS_OK
+    assert lib.kws_ctc_decode(7, None, None, 1, 1, 6, 3, 0.5, 0.2, None, None, 0, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_ctc_decode(_lib.DECODE, None, None, 1, 1, 4, 3, 0.5, 0.2, None, None, 0, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_octbit_matmul(None, None, 0.0, None, None, 1, 64, 1, 0, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert b"positive" in lib.kws_last_error()
+    assert lib.kws_octbit_matmul(None, None, 1.0, None, None, 1, 63, 1, 0, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert b"multiple of 64" in lib.kws_last_error()
+    assert lib.kws_ctc_predict(None, None, 1, 1, b"12x", None, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    with pytest.raises(_lib.InvalidArgumentError):
+        _lib.check(_lib.KWS_ERR_INVALID_ARGUMENT)
+    with pytest.raises(_lib.UnsupportedError):
+        _lib.check(_lib.KWS_ERR_UNSUPPORTED)
+
+
+def test_host_side_quantiser_matches_oracle():
+    """kws_octbit_quantize is host code (octbit/octbit_graph.py:191-215): checkable without a GPU."""
+    from keyword_spotting_amd.octbit_graph import octize_weight_int8_signed
+    from oracle import octbit_oracle as O
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((128, 24)) * 0.2).astype(np.float32)
+    w[3, 5] = 2.5 * np.abs(w).max()                     # tie-prone scale
+    wq, scale, bias = octize_weight_int8_signed(w)
+    wq2, scale2, bias2 = O.octize_weight_int8_signed(w)
+    np.testing.assert_array_equal(wq, wq2)
+    assert scale == np.float32(scale2)
+    np.testing.assert_array_equal(bias, bias2.astype(np.float32))
+
+
+@pytest.mark.skipif(have_gpu(), reason="checks the no-GPU failure mode")
+def test_no_silent_cpu_fallback():
+    from keyword_spotting_amd import _lib, get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    lib = _lib.load()
+    cfg = _lib.KwsConfig(40, 128, 2, 6, 0, -1.0)
+    blob = np.zeros(657432 // 4, np.float32)
+    h = ctypes.c_void_p()
+    rc = lib.kws_create(ctypes.byref(cfg), blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes, ctypes.byref(h))
+    assert rc == _lib.KWS_ERR_NO_DEVICE and not h.value
+    with pytest.raises(Exception):
+        DeployModel(get_config(), blob, device="cuda:0")
+    with pytest.raises(_lib.InvalidArgumentError):
+        DeployModel(get_config(), blob, device="cpu")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "keyword_spotting_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "kws_oracle" not in text, f

@@ -1,0 +1,230 @@
+"""HIP GRU path vs the oracle, through the C ABI (kws_step).  Tolerance from north_star: logits
+within 1e-4, identical collapsed keyword decisions (margin-aware at the hard thresholds)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_oracle as D
+from oracle import gru_oracle as G
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _model(shape, w, kernel="auto", **cfg_kw):
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    i, h, l, c = shape
+    cfg = get_config(n_mel=i, hidden_size=h, num_layers=l, **cfg_kw)
+    if c != 6:
+        cfg.label_dict = {str(k): k for k in range(1, c - 2)}
+    return DeployModel(cfg, w, kernel=kernel)
+
+
+def _cfg_tuple(shape, use_relu=0, clip=-1.0):
+    return shape + (use_relu, clip)
+
+
+SHAPES = {"A": (40, 128, 2, 6), "B": (60, 128, 2, 6), "C": (60, 256, 4, 6)}
+
+
+@pytest.mark.parametrize("name,kernel,batch,frames", [
+    ("A", "resident", 37, 50), ("A", "generic", 37, 50), ("A", "resident", 1, 300),
+    ("A", "resident", 16, 1), ("A", "resident", 33, 7), ("B", "resident", 20, 23), ("B", "generic", 5, 22),
+    ("C", "generic", 20, 12), ("C", "auto", 3, 40)])
+def test_logits_state_softmax_match_oracle(oracle_c, name, kernel, batch, frames):
+    shape = SHAPES[name]
+    i, h, l, c = shape
+    w = G.random_weights(i, h, l, c, seed=21)
+    mel = G.synthetic_mel(batch, frames, i, seed=22)
+    st0 = (0.5 * np.random.default_rng(23).standard_normal((l, batch, h))).astype(np.float32)
+    want_l, want_s = G.gru_forward(w, mel, st0, dtype=np.float64)
+    m = _model(shape, w, kernel)
+    r = m.forward(torch.from_numpy(mel), torch.from_numpy(st0))
+    got_l, got_sm, got_s = r["logits"].cpu().numpy(), r["softmax"].cpu().numpy(), r["state"].cpu().numpy()
+    assert np.abs(got_l - want_l).max() < TOL
+    assert np.abs(got_s - want_s).max() < TOL
+    assert np.abs(got_sm - G.softmax(want_l)).max() < 2e-5
+    np.testing.assert_allclose(got_sm.sum(-1), 1.0, atol=1e-6)
+    # and against the C restatement (what bench.py times as the CPU baseline)
+    c_l, _, c_s = oracle_c.gru_forward(_cfg_tuple(shape), G.weights_to_blob(w), mel, st0)
+    assert np.abs(got_l - c_l).max() < TOL and np.abs(got_s - c_s).max() < TOL
+
+
+def test_resident_and_generic_kernels_agree():
+    w = G.random_weights(40, 128, 2, 6, seed=31)
+    mel = torch.from_numpy(G.synthetic_mel(48, 64, 40, seed=32))
+    a = _model(SHAPES["A"], w, "resident")
+    b = _model(SHAPES["A"], w, "generic")
+    ra, rb = a.forward(mel, a.zero_state(48)), b.forward(mel, b.zero_state(48))
+    assert (ra["logits"] - rb["logits"]).abs().max().item() < 2e-5   # same math, different K order
+    assert (ra["state"] - rb["state"]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("kernel", ["resident", "generic"])
+def test_chunked_streaming_equals_one_shot_bitwise(kernel):
+    """detector.py:254-289 test2: feeding 21/22/23-frame chunks with the carried state must give the
+    single-call result -- bit-exact on the GPU, every frame runs the identical instruction sequence."""
+    w = G.init_weights()
+    mel = torch.from_numpy(G.synthetic_mel(19, 300)).cuda()
+    m = _model(SHAPES["A"], w, kernel)
+    whole = m.forward(mel, m.zero_state(19))
+    state, outs, pos = m.zero_state(19), [], 0
+    for n in D.chunk_frame_counts([3600] * 13) + [300 - sum(D.chunk_frame_counts([3600] * 13))]:
+        lg, state = m.step(mel[:, pos:pos + n].contiguous(), state)
+        outs.append(lg)
+        pos += n
+    assert pos == 300
+    assert torch.equal(torch.cat(outs, 1), whole["logits"])
+    assert torch.equal(state, whole["state"])
+
+
+def test_state_may_alias_and_empty_calls():
+    w = G.init_weights()
+    m = _model(SHAPES["A"], w)
+    mel = torch.from_numpy(G.synthetic_mel(4, 9)).cuda()
+    st = (0.1 * torch.randn(2, 4, 128, device="cuda"))
+    ref = m.forward(mel, st.clone())
+    st2 = st.clone()
+    r = m.forward(mel, st2, state_out=st2)                       # in place
+    assert torch.equal(r["state"], ref["state"]) and r["state"].data_ptr() == st2.data_ptr()
+    e = m.forward(mel[:, :0].contiguous(), st)                   # T == 0: state passes through
+    assert torch.equal(e["state"], st) and e["logits"].shape == (4, 0, 6)
+    e = m.forward(mel[:0].contiguous(), st[:, :0].contiguous())  # B == 0
+    assert e["logits"].shape == (0, 9, 6)
+
+
+@pytest.mark.parametrize("kernel", ["resident", "generic"])
+def test_sequence_length_and_reset_mask(kernel):
+    w = G.random_weights(40, 128, 2, 6, seed=41)
+    b, t = 21, 30
+    mel = G.synthetic_mel(b, t, 40, seed=42)
+    rng = np.random.default_rng(43)
+    st0 = (0.5 * rng.standard_normal((2, b, 128))).astype(np.float32)
+    lens = rng.integers(0, t + 1, b).astype(np.int32)
+    lens[:3] = [0, t, 1]
+    reset = (rng.random(b) < 0.4).astype(np.uint8)
+    st_ref = st0 * (1 - reset)[None, :, None]
+    want_l, want_s = G.gru_forward(w, mel, st_ref, seq_len=lens, dtype=np.float64)
+    m = _model(SHAPES["A"], w, kernel)
+    r = m.forward(torch.from_numpy(mel), torch.from_numpy(st0), seq_len=torch.from_numpy(lens),
+                  reset_mask=torch.from_numpy(reset))
+    assert np.abs(r["logits"].cpu().numpy() - want_l).max() < TOL
+    assert np.abs(r["state"].cpu().numpy() - want_s).max() < TOL
+    # rows past seq_len are exactly the bias row (zero output of dynamic_rnn)
+    got = r["logits"].cpu().numpy()
+    for k in range(b):
+        np.testing.assert_array_equal(got[k, lens[k]:], np.broadcast_to(w["bfc"], (t - lens[k], 6)))
+
+
+def test_relu_and_clip():
+    w = G.random_weights(40, 128, 2, 6, seed=51)
+    w["Wfc"] *= 20
+    mel = G.synthetic_mel(6, 25, 40, seed=52)
+    want, _ = G.gru_forward(w, mel, use_relu=True, value_clip=1.0, dtype=np.float64)
+    m = _model(SHAPES["A"], w, use_relu=True, value_clip=1.0)
+    got = m.forward(torch.from_numpy(mel), m.zero_state(6))["logits"].cpu().numpy()
+    assert np.abs(got - want).max() < 2e-3 * 20 / 20 + 5e-4      # logits up to 20: relative 1e-4-class
+    assert got.min() == 0.0 and got.max() == 20.0
+
+
+def _margin_ok(softmax_row, thres, eps=1e-4):
+    p = softmax_row[1:5]
+    srt = np.sort(p)
+    return abs(p.max() - thres) > eps and (srt[-1] - srt[-2]) > eps
+
+
+@pytest.mark.parametrize("kernel", ["resident", "generic"])
+def test_fused_decode2_tokens_and_carry(kernel):
+    """Fused per-frame ctc_decode2 events == reference rule on the oracle's softmax; pre_word is
+    carried across chunk boundaries (== decoding the concatenation)."""
+    w = G.init_weights()
+    b, t = 40, 120
+    mel = G.synthetic_mel(b, t, 40, seed=61)
+    want_l, _ = G.gru_forward(w, mel, dtype=np.float64)
+    want_sm = G.softmax(want_l)
+    m = _model(SHAPES["A"], w, kernel)
+    state, pw = m.zero_state(b), m.fresh_prev_word(b)
+    toks, pos = [], 0
+    melc = torch.from_numpy(mel).cuda()
+    for n in (21, 22, 23, 22, 1, 31):
+        r = m.forward(melc[:, pos:pos + n].contiguous(), state, prev_word=pw)
+        state = r["state"]
+        toks.append(r["tokens"])
+        pos += n
+    assert pos == t
+    toks = torch.cat(toks, 1).cpu().numpy()
+    from keyword_spotting_amd.prediction import tokens_to_seq
+    checked = 0
+    for k in range(b):
+        if not all(_margin_ok(row, 0.4) for row in want_sm[k]):
+            continue                                   # a frame sits within 1e-4 of the threshold / a tie
+        np.testing.assert_array_equal(tokens_to_seq(toks[k]), D.ctc_decode2(want_sm[k], 6), err_msg=str(k))
+        checked += 1
+    assert checked >= b // 2
+    assert (toks > 0).sum() > b                       # the decode is not vacuous
+    # carried pre_word == word of the last frame
+    last = D.frame_words(want_sm[:, -1, :].reshape(b, 6), 1, 5, 0.4)
+    ok = [k for k in range(b) if _margin_ok(want_sm[k, -1], 0.4)]
+    np.testing.assert_array_equal(pw.cpu().numpy()[ok], last[ok])
+
+
+def test_errors_are_reported_not_fatal():
+    from keyword_spotting_amd import _lib, get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    w = G.init_weights()
+    m = _model(SHAPES["A"], w)
+    with pytest.raises(_lib.InvalidArgumentError):
+        m.forward(torch.zeros(2, 5, 41), m.zero_state(2))          # wrong n_mel
+    with pytest.raises(_lib.InvalidArgumentError):
+        m.forward(torch.zeros(2, 5, 40), m.zero_state(3))          # state batch mismatch
+    with pytest.raises(_lib.InvalidArgumentError):
+        m.run(["model/nope:0"], {"model/inputX:0": torch.zeros(5, 40), "model/rnn_initial_states:0": m.zero_state(1)})
+    with pytest.raises(_lib.UnsupportedError):
+        DeployModel(get_config(hidden_size=100), np.zeros(10, np.float32))
+    with pytest.raises(_lib.InvalidArgumentError):
+        DeployModel(get_config(), np.zeros(10, np.float32))        # blob size
+    with pytest.raises(_lib.UnsupportedError):
+        _model((50, 128, 2, 6), G.init_weights(50), "resident")
+
+
+def test_session_run_surface_batch1():
+    """detector.py:190-193 vocabulary at batch 1: 2-D softmax [T,C], 3-D logit [1,T,C], state [L,1,H]."""
+    w = G.init_weights()
+    m = _model(SHAPES["A"], w)
+    mel = G.synthetic_mel(1, 22)
+    softmax, state = m.run(["model/softmax:0", "model/rnn_states:0"],
+                           {"model/inputX:0": mel[0], "model/rnn_initial_states:0": np.zeros((2, 1, 128), np.float32)})
+    assert tuple(softmax.shape) == (22, 6) and tuple(state.shape) == (2, 1, 128)
+    logit = m.run("model/logit:0", {"model/inputX:0": mel[0], "model/rnn_initial_states:0": m.zero_state(1)})
+    assert tuple(logit.shape) == (1, 22, 6)
+    want_l, want_s = G.gru_forward(w, mel, dtype=np.float64)
+    assert np.abs(logit.cpu().numpy() - want_l).max() < TOL
+    assert np.abs(softmax.cpu().numpy() - G.softmax(want_l)[0]).max() < 2e-5
+
+
+def test_full_size_properties(oracle_c):
+    """BASELINE config 2 at full size (B=4096, T=300): (i) a sample of streams against the C oracle,
+    (ii) batch-composition independence: a stream's result does not depend on its batch neighbours
+    (what multi-GPU sharding relies on), (iii) chunked == one-shot, bitwise."""
+    w = G.init_weights()
+    b, t = 4096, 300
+    rng = torch.Generator(device="cpu").manual_seed(71)
+    mel = (torch.randn(b, t, 40, generator=rng).abs() * 2).cuda()
+    m = _model(SHAPES["A"], w)
+    whole = m.forward(mel, m.zero_state(b))
+    pick = [0, 1, 15, 16, 17, 2047, 2048, 4079, 4080, 4095] + list(range(100, 4000, 211))
+    sub = mel[pick].cpu().numpy()
+    c_l, _, c_s = oracle_c.gru_forward(_cfg_tuple(SHAPES["A"]), G.weights_to_blob(w), sub,
+                                       np.zeros((2, len(pick), 128), np.float32), threads=4)
+    assert np.abs(whole["logits"][pick].cpu().numpy() - c_l).max() < TOL
+    assert np.abs(whole["state"][:, pick].cpu().numpy() - c_s).max() < TOL
+    part = m.forward(mel[pick].contiguous(), m.zero_state(len(pick)))
+    assert torch.equal(part["logits"], whole["logits"][pick])
+    assert torch.equal(part["state"], whole["state"][:, pick])
+    state, pos = m.zero_state(b), 0
+    for n in (150, 22, 128):
+        lg, state = m.step(mel[:, pos:pos + n].contiguous(), state)
+        assert torch.equal(lg, whole["logits"][:, pos:pos + n])
+        pos += n
+    assert torch.equal(state, whole["state"])
