@@ -18,6 +18,8 @@
 //     mel / previous layer's h stream is read per step.
 //   * x-part MFMAs of frame t+1 are issued behind frame t's two barriers (software pipeline), so
 //     the LDS exchange latency overlaps independent matrix work.
+#include <type_traits>
+
 #include "kws_internal.h"
 
 namespace kws {
@@ -36,6 +38,11 @@ __device__ __forceinline__ float tanh_f(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
 }
 __device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
+// exact, branch-free select: m = all-ones -> a, m = 0 -> b (v_bfi_b32); keeps the h update one
+// straight-line block so MFMAs can be scheduled through it
+__device__ __forceinline__ float bitsel(unsigned m, float a, float b) {
+    return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+}
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // ------------------------------------------------------------------------------------------------
@@ -211,18 +218,29 @@ gru_layer_resident(const GruLayerParams p) {
     };
 
     f32x4 acc_r[2], acc_u[2], acc_c[2];
-    auto gates_x = [&]() {
+    // gate x-part for k-chunks [K0, K1): A fragments stream from LDS through a 3-deep register ring
+    // (two ds_read_b128 in flight behind the MFMAs that consume the third)
+    auto gates_x_part = [&](auto k0_, auto k1_) {
+        constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+        f32x4 ring[3];
+        if (K0 < K1) ring[K0 % 3] = wlds[(w * KCX + K0) * 64 + lane];
+        if (K0 + 1 < K1) ring[(K0 + 1) % 3] = wlds[(w * KCX + K0 + 1) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
-#pragma unroll
-        for (int kc = 0; kc < KCX; ++kc) {
-            const f32x4 a4 = wlds[(w * KCX + kc) * 64 + lane];
+        for (int kc = K0; kc < K1; ++kc) {
+            if (kc + 2 < K1) ring[(kc + 2) % 3] = wlds[(w * KCX + kc + 2) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);   // keep the read two groups ahead of its MFMAs
+            const f32x4 a4 = ring[kc % 3];
             acc_r[0] = mfma4(a4.x, xB[kc], acc_r[0]);
             acc_u[0] = mfma4(a4.y, xB[kc], acc_u[0]);
             acc_r[1] = mfma4(a4.z, xB[kc], acc_r[1]);
             acc_u[1] = mfma4(a4.w, xB[kc], acc_u[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
+    constexpr int KSPLIT = KCX / 2;
+    using k_lo = std::integral_constant<int, 0>;
+    using k_mid = std::integral_constant<int, KSPLIT>;
+    using k_hi = std::integral_constant<int, KCX>;
     auto cand_x = [&]() {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_c[j] = bias_c[j];
@@ -234,20 +252,30 @@ gru_layer_resident(const GruLayerParams p) {
     };
 
     __syncthreads();
+    f32x4 hb_a, hb_b;            // exchange-read pipeline registers (two float4 in flight)
     if (T > 0) {
         load_x(0);
-        gates_x();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
+        gates_x_part(k_lo{}, k_hi{});
+        hb_a = hbuf[0 * 64 + lane];
+        hb_b = hbuf[1 * 64 + lane];
         cand_x();
     }
 
     for (int t = 0; t < T; ++t) {
-        // x of frame t+1: in flight while this frame's recurrent half runs
+        // x of frame t+1: in flight while this frame's recurrent half runs (x of frame t is dead:
+        // both of its x-part products were issued during frame t-1)
         load_x(t + 1 < T ? t + 1 : T - 1);
 
-        // gates, h-part:  acc_{r,u} += Wg[I:,:]^T h_{t-1}
+        // gates, h-part:  acc_{r,u} += Wg[I:,:]^T h_{t-1}   (hb_a/hb_b were fetched behind cand_x)
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
-            const f32x4 hb = hbuf[nn * 64 + lane];
+            const f32x4 hb = (nn & 1) ? hb_b : hb_a;
+            if (nn + 2 < NT) {
+                if (nn & 1) hb_b = hbuf[(nn + 2) * 64 + lane]; else hb_a = hbuf[(nn + 2) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kc = 4 * nn + e;
@@ -268,13 +296,23 @@ gru_layer_resident(const GruLayerParams p) {
             }
             rhbuf[(2 * w + j) * 64 + lane] = rh;
         }
-        gates_x();            // frame t+1, independent of the exchange below
+        // frame t+1 gate x-part, first half: independent of the exchange, fills the barrier skew
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
+        gates_x_part(k_lo{}, k_mid{});
         __syncthreads();      // #1: r(.)h visible; every wave is done reading hbuf
+        hb_a = rhbuf[0 * 64 + lane];
+        hb_b = rhbuf[1 * 64 + lane];
+        gates_x_part(k_mid{}, k_hi{});     // second half hides the rhbuf read latency
 
         // candidate, h-part:  acc_c += Wc[I:,:]^T (r (.) h_{t-1})
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
-            const f32x4 rb = rhbuf[nn * 64 + lane];
+            const f32x4 rb = (nn & 1) ? hb_b : hb_a;
+            if (nn + 2 < NT) {
+                if (nn & 1) hb_b = rhbuf[(nn + 2) * 64 + lane]; else hb_a = rhbuf[(nn + 2) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kc = 4 * nn + e;
@@ -282,7 +320,7 @@ gru_layer_resident(const GruLayerParams p) {
                 acc_c[1] = mfma4(wch[1][kc], rb[e], acc_c[1]);
             }
         }
-        const bool live = t < len_s;       // dynamic_rnn copy-through past seq_len
+        const unsigned live = t < len_s ? 0xffffffffu : 0u;   // dynamic_rnn copy-through past seq_len
         f32x4 hout[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -290,8 +328,8 @@ gru_layer_resident(const GruLayerParams p) {
             for (int e = 0; e < 4; ++e) {
                 const float c = tanh_f(acc_c[j][e]);
                 const float hn = u[j][e] * hreg[j][e] + (1.0f - u[j][e]) * c;
-                hreg[j][e] = live ? hn : hreg[j][e];
-                hout[j][e] = live ? hn : 0.f;
+                hreg[j][e] = bitsel(live, hn, hreg[j][e]);
+                hout[j][e] = bitsel(live, hn, 0.f);
             }
             hbuf[(2 * w + j) * 64 + lane] = hreg[j];
             if (!LAST) {
@@ -310,8 +348,10 @@ gru_layer_resident(const GruLayerParams p) {
             if (g < 2)
                 *reinterpret_cast<f32x4*>(stage + ((w * kFlushSteps + (t & (kFlushSteps - 1))) * 16 + s) * 8 + 4 * g) = accf;
         }
-        cand_x();             // frame t+1
         __syncthreads();      // #2: h_t visible; every wave is done reading rhbuf
+        hb_a = hbuf[0 * 64 + lane];
+        hb_b = hbuf[1 * 64 + lane];
+        cand_x();             // frame t+1; hides the hbuf read latency
         if (LAST && w == 0 && (((t + 1) & (kFlushSteps - 1)) == 0 || t == T - 1)) {
             const int t0 = t & ~(kFlushSteps - 1);
             flush_logits(p, stage, carry, group, t0, t - t0 + 1, lane, t == T - 1);
@@ -450,7 +490,7 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
                 for (int e = 0; e < 4; ++e) acc_c[j] = mfma4(ac[e], rb[e], acc_c[j]);
             }
         }
-        const bool live = t < len_s;
+        const unsigned live = t < len_s ? 0xffffffffu : 0u;
         f32x4 accf = bfc4;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
@@ -460,8 +500,8 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
             for (int e = 0; e < 4; ++e) {
                 const float c = tanh_f(acc_c[j][e]);
                 const float hn = u[j][e] * hreg[j][e] + (1.0f - u[j][e]) * c;
-                hreg[j][e] = live ? hn : hreg[j][e];
-                hout[e] = live ? hn : 0.f;
+                hreg[j][e] = bitsel(live, hn, hreg[j][e]);
+                hout[e] = bitsel(live, hn, 0.f);
             }
             hbuf[n * 64 + lane] = hreg[j];
             if (!LAST) {

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (kernel stats + PMC passes) into a small text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+for f in find("trace/**/*kernel_stats.csv"):
+    print("== kernel stats (%s)" % os.path.relpath(f, out))
+    for row in csv.DictReader(open(f)):
+        name = row.get("Name", "")[:90]
+        print("%-90s calls=%s total_ns=%s avg_ns=%s pct=%s" % (name, row.get("Calls"), row.get("TotalDurationNs"),
+                                                              row.get("AverageNs"), row.get("Percentage")))
+for d in find("pmc*/"):
+    for f in find(os.path.relpath(d, out) + "/**/*counter_collection.csv"):
+        print("== counters (%s)" % os.path.relpath(f, out))
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(int)
+        for row in csv.DictReader(open(f)):
+            k = row.get("Kernel_Name", "")[:70]
+            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            cnt[(k, row["Counter_Name"])] += 1
+        for k, ctrs in acc.items():
+            if "gru_layer" not in k:
+                continue
+            print(k)
+            for name, v in sorted(ctrs.items()):
+                n = cnt[(k, name)]
+                print("    %-28s per-dispatch %.6g  (dispatches %d)" % (name, v / n, n))
