@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkws_amd.so")
+LIB_PATH = os.environ.get("KWS_AMD_LIB", os.path.join(_HERE, "libkws_amd.so"))   # override: timing experiments
 
 KWS_OK = 0
 KWS_ERR_INVALID_ARGUMENT = -1

@@ -31,11 +31,64 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 // sigma(x) = 1/(1+e^-x).  v_exp_f32 path: abs error <= 3e-7 on [-30,30]; saturates cleanly.
 __device__ __forceinline__ float sigmoid_f(float x) {
+#ifdef KWS_ABL_NOVALU
+    return x * 0.001f;
+#else
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+#endif
 }
 // tanh(x) = 1 - 2/(1+e^{2x}); abs error <= 3e-7, exact limits +-1.
 __device__ __forceinline__ float tanh_f(float x) {
+#ifdef KWS_ABL_NOVALU
+    return x * 0.001f;
+#else
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+#endif
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every frame
+// would then wait for the inter-layer scratch stores and for the x prefetch of the next frame, which
+// no other wave of the group ever reads.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#if defined(KWS_TIMING) && defined(KWS_ABL_NOBARRIER)
+#define KWS_TIMING_BAR() do {} while (0)
+#else
+#define KWS_TIMING_BAR() __builtin_amdgcn_s_barrier()
+#endif
+#if defined(KWS_TIMING)
+// timing variant: s_memtime around each barrier (lgkmcnt is drained there anyway)
+#define KWS_SYNC_T(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long ta_ = __builtin_readcyclecounter(); \
+    KWS_TIMING_BAR(); const unsigned long long tb_ = __builtin_readcyclecounter(); \
+    seg_[i] += ta_ - tlast_; wait_[i] += tb_ - ta_; tlast_ = tb_; asm volatile("" ::: "memory"); } while (0)
+#endif
+#if defined(KWS_ABL_NOBARRIER)
+#define KWS_SYNC() __builtin_amdgcn_sched_barrier(0)
+#elif defined(KWS_ABL_WAITONLY)
+#define KWS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#elif defined(KWS_ABL_BARONLY)
+#define KWS_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(KWS_ABL_SYNCTHREADS)
+#define KWS_SYNC() __syncthreads()
+#else
+#define KWS_SYNC() lds_barrier()
+#endif
+// MFMA whose A operand (a resident weight fragment) is read straight from the AGPR half of the
+// unified register file.  hipcc only ever parks such values in AGPRs as spills and re-reads them with
+// v_accvgpr_read + s_nop (39 cycles per MFMA instead of 32, tools/ubench/mfma_issue.hip); the "a"
+// constraint removes the copy.  The statement is opaque to the hazard recogniser: every chain of these
+// ends with mfma_fence() before any non-MFMA instruction touches the accumulators.
+#define KWS_MFMA_A(acc, wa, bv) \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(wa), "v"(bv))
+// XDL 8-pass write -> VALU read needs 11 wait states (s_nop 15 = 16); the "+v" ties order it after the
+// chain and ahead of every consumer
+__device__ __forceinline__ void mfma_fence(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void mfma_fence(f32x4& a, f32x4& b) {
+    asm volatile("s_nop 15" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
 // exact, branch-free select: m = all-ones -> a, m = 0 -> b (v_bfi_b32); keeps the h update one
@@ -43,6 +96,14 @@ __device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; retur
 __device__ __forceinline__ float bitsel(unsigned m, float a, float b) {
     return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
 }
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+constexpr float kLog2e = 1.4426950408889634f;
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // ------------------------------------------------------------------------------------------------
@@ -58,12 +119,16 @@ __device__ __forceinline__ void flush_logits(const GruLayerParams& p, const floa
     const int b = group * kStreamsPerGroup + s;
     const int C = p.C;
     float lg[kMaxClasses];
+    {
+        f32x4 lo = splat4(0.f), hi = splat4(0.f);
 #pragma unroll
-    for (int c = 0; c < kMaxClasses; ++c) {
-        float v = 0.f;
+        for (int w = 0; w < 4; ++w) {
+            const f32x4* row = reinterpret_cast<const f32x4*>(stage + ((w * kFlushSteps + tt) * 16 + s) * 8);
+            lo += row[0];
+            hi += row[1];
+        }
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += stage[((w * kFlushSteps + tt) * 16 + s) * 8 + c];
-        lg[c] = v;
+        for (int c = 0; c < 4; ++c) { lg[c] = lo[c]; lg[4 + c] = hi[c]; }
     }
     if (p.use_relu) {
 #pragma unroll
@@ -79,10 +144,10 @@ __device__ __forceinline__ void flush_logits(const GruLayerParams& p, const floa
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < kMaxClasses; ++c) {
-        pr[c] = (c < C) ? expf(lg[c] - m) : 0.f;
+        pr[c] = (c < C) ? __expf(lg[c] - m) : 0.f;     // arguments <= 0: abs error < 1e-7
         sum += pr[c];
     }
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
     for (int c = 0; c < kMaxClasses; ++c) pr[c] *= inv;
     // ctc_decode2 frame rule over classes 1..C-2 (utils/prediction.py:67,74-75): first maximum, strict >
@@ -99,15 +164,26 @@ __device__ __forceinline__ void flush_logits(const GruLayerParams& p, const floa
     if (tt == n - 1) carry[s] = word;
     if (b < p.B && tt < n) {
         const size_t row = (size_t)b * p.T + (t0 + tt);
-        if (p.logits) {
+        if (C == 6) {       // rows are 24 B: three 8-byte stores
+            if (p.logits) {
+                float2* o = reinterpret_cast<float2*>(p.logits + row * 6);
+                o[0] = make_float2(lg[0], lg[1]); o[1] = make_float2(lg[2], lg[3]); o[2] = make_float2(lg[4], lg[5]);
+            }
+            if (p.softmax) {
+                float2* o = reinterpret_cast<float2*>(p.softmax + row * 6);
+                o[0] = make_float2(pr[0], pr[1]); o[1] = make_float2(pr[2], pr[3]); o[2] = make_float2(pr[4], pr[5]);
+            }
+        } else {
+            if (p.logits) {
 #pragma unroll
-            for (int c = 0; c < kMaxClasses; ++c)
-                if (c < C) p.logits[row * C + c] = lg[c];
-        }
-        if (p.softmax) {
+                for (int c = 0; c < kMaxClasses; ++c)
+                    if (c < C) p.logits[row * C + c] = lg[c];
+            }
+            if (p.softmax) {
 #pragma unroll
-            for (int c = 0; c < kMaxClasses; ++c)
-                if (c < C) p.softmax[row * C + c] = pr[c];
+                for (int c = 0; c < kMaxClasses; ++c)
+                    if (c < C) p.softmax[row * C + c] = pr[c];
+            }
         }
         if (p.tokens) p.tokens[row] = (int8_t)token;
         if (final_flush && tt == n - 1 && p.prev_word) p.prev_word[b] = word;
@@ -154,6 +230,17 @@ gru_layer_resident(const GruLayerParams p) {
 #pragma unroll
         for (int kc = 0; kc < KCX; ++kc) wcx[j][kc] = p.wx[((n * 3 + 2) * KCX + kc) * 64 + lane];
     }
+    // park the recurrent fragments in AGPRs for the whole launch (192 of the 256)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            asm volatile("" : "+a"(wgh[j][0][kc]));
+            asm volatile("" : "+a"(wgh[j][1][kc]));
+            asm volatile("" : "+a"(wch[j][kc]));
+        }
+    }
+    asm volatile("s_nop 7" ::: "memory");   // v_accvgpr_write -> MFMA SrcA distance
     for (int kc = 0; kc < KCX; ++kc) {
         f32x4 v;
         v.x = p.wx[((n0 * 3 + 0) * KCX + kc) * 64 + lane];
@@ -198,50 +285,64 @@ gru_layer_resident(const GruLayerParams p) {
     }
 
     // ---- x stream --------------------------------------------------------------------------------
+    // First layer: mel rows, prefetched TWO frames ahead into a double buffer.  vmcnt counts stores
+    // too, so with a one-frame distance the wait for x(t+1) would also wait for the acks of frame
+    // t-1's scratch stores (issued just before the loads) and the jitter would surface as barrier skew.
+    // Upper layers: the previous layer's xl-layout block, one frame ahead (32 registers, no room for two).
+    constexpr int XD = FIRST ? 2 : 1;
     const float* xrow = FIRST ? p.x_mel + (size_t)b * T * p.I : nullptr;
     const float4* xprev = FIRST ? nullptr : p.x_prev + (size_t)group * T * NT * 64 + lane;
-    float xB[KCX];
-    auto load_x = [&](int t) {
-        if (FIRST) {
+    float xbuf0[KCX], xbuf1[KCX];   // xbuf1 is dead (and removed) when XD == 1
+    // x is fetched in NT slices so the loads can be dripped into the instruction stream one per MFMA
+    // group: a burst of 10 divergent loads issued by four phase-locked waves at once backs up the
+    // address path and, issue being in order, stalls the MFMAs queued behind it (~900 cycles/frame).
+    auto load_x_slice = [&](float (&dst)[KCX], int t_req, const int sl) {   // sl: unrolled constant
+        const int t = t_req < T ? t_req : T - 1;
+        if constexpr (FIRST) {
 #pragma unroll
-            for (int kc = 0; kc < KCX; ++kc) {
+            for (int kc = sl; kc < KCX; kc += NT) {
+                // rows k >= I carry zero weights: clamp the address instead of predicating the load
                 const int k = 4 * kc + g;
-                xB[kc] = (k < p.I) ? xrow[(size_t)t * p.I + k] : 0.f;
+                dst[kc] = xrow[(size_t)t * p.I + (k < p.I ? k : p.I - 1)];
             }
         } else {
-#pragma unroll
-            for (int nn = 0; nn < KCX / 4; ++nn) {
-                const float4 v = xprev[((size_t)t * NT + nn) * 64];
-                xB[4 * nn + 0] = v.x; xB[4 * nn + 1] = v.y; xB[4 * nn + 2] = v.z; xB[4 * nn + 3] = v.w;
-            }
+            const float4 v = xprev[((size_t)t * NT + sl) * 64];
+            dst[4 * sl + 0] = v.x; dst[4 * sl + 1] = v.y; dst[4 * sl + 2] = v.z; dst[4 * sl + 3] = v.w;
         }
+    };
+    auto load_x = [&](float (&dst)[KCX], int t_req) {
+#pragma unroll
+        for (int sl = 0; sl < NT; ++sl) load_x_slice(dst, t_req, sl);
     };
 
     f32x4 acc_r[2], acc_u[2], acc_c[2];
     // gate x-part for k-chunks [K0, K1): A fragments stream from LDS through a 3-deep register ring
     // (two ds_read_b128 in flight behind the MFMAs that consume the third)
-    auto gates_x_part = [&](auto k0_, auto k1_) {
+    auto gates_x_part = [&](const float (&xB)[KCX], auto k0_, auto k1_, auto pin_) {
         constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+        constexpr bool PIN = decltype(pin_)::value;
         f32x4 ring[3];
         if (K0 < K1) ring[K0 % 3] = wlds[(w * KCX + K0) * 64 + lane];
         if (K0 + 1 < K1) ring[(K0 + 1) % 3] = wlds[(w * KCX + K0 + 1) * 64 + lane];
 #pragma unroll
         for (int kc = K0; kc < K1; ++kc) {
             if (kc + 2 < K1) ring[(kc + 2) % 3] = wlds[(w * KCX + kc + 2) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);   // keep the read two groups ahead of its MFMAs
+            if (PIN) __builtin_amdgcn_sched_barrier(0);   // keep the read two groups ahead of its MFMAs
             const f32x4 a4 = ring[kc % 3];
             acc_r[0] = mfma4(a4.x, xB[kc], acc_r[0]);
             acc_u[0] = mfma4(a4.y, xB[kc], acc_u[0]);
             acc_r[1] = mfma4(a4.z, xB[kc], acc_r[1]);
             acc_u[1] = mfma4(a4.w, xB[kc], acc_u[1]);
-            __builtin_amdgcn_sched_barrier(0);
+            if (PIN) __builtin_amdgcn_sched_barrier(0);
         }
     };
+    using pinned = std::true_type;
+    using unpinned = std::false_type;
     constexpr int KSPLIT = KCX / 2;
     using k_lo = std::integral_constant<int, 0>;
     using k_mid = std::integral_constant<int, KSPLIT>;
     using k_hi = std::integral_constant<int, KCX>;
-    auto cand_x = [&]() {
+    auto cand_x = [&](const float (&xB)[KCX]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_c[j] = bias_c[j];
 #pragma unroll
@@ -252,58 +353,95 @@ gru_layer_resident(const GruLayerParams p) {
     };
 
     __syncthreads();
+#ifdef KWS_TIMING
+    unsigned long long seg_[2] = {0, 0}, wait_[2] = {0, 0}, tlast_ = __builtin_readcyclecounter();
+    const unsigned long long tstart_ = tlast_;
+#endif
     f32x4 hb_a, hb_b;            // exchange-read pipeline registers (two float4 in flight)
-    if (T > 0) {
-        load_x(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
-        gates_x_part(k_lo{}, k_hi{});
-        hb_a = hbuf[0 * 64 + lane];
-        hb_b = hbuf[1 * 64 + lane];
-        cand_x();
-    }
 
-    for (int t = 0; t < T; ++t) {
-        // x of frame t+1: in flight while this frame's recurrent half runs (x of frame t is dead:
-        // both of its x-part products were issued during frame t-1)
-        load_x(t + 1 < T ? t + 1 : T - 1);
-
-        // gates, h-part:  acc_{r,u} += Wg[I:,:]^T h_{t-1}   (hb_a/hb_b were fetched behind cand_x)
+    // One frame.  xcur holds x(t+1) on entry (XD == 2) or receives it first (XD == 1, xcur == xnxt);
+    // xnxt receives x(t+XD).
+    auto frame = [&](int t, float (&xcur)[KCX], float (&xnxt)[KCX]) {
+        // gates, h-part:  acc_{r,u} += Wg[I:,:]^T h_{t-1}   (hb_a/hb_b were fetched behind cand_x);
+        // one slice of x(t+XD) is requested per group
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const f32x4 hb = (nn & 1) ? hb_b : hb_a;
             if (nn + 2 < NT) {
                 if (nn & 1) hb_b = hbuf[(nn + 2) * 64 + lane]; else hb_a = hbuf[(nn + 2) * 64 + lane];
             }
+            load_x_slice(xnxt, t + XD, nn);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kc = 4 * nn + e;
-                acc_r[0] = mfma4(wgh[0][0][kc], hb[e], acc_r[0]);
-                acc_u[0] = mfma4(wgh[0][1][kc], hb[e], acc_u[0]);
-                acc_r[1] = mfma4(wgh[1][0][kc], hb[e], acc_r[1]);
-                acc_u[1] = mfma4(wgh[1][1][kc], hb[e], acc_u[1]);
+                const float hv = hb[e];
+                KWS_MFMA_A(acc_r[0], wgh[0][0][kc], hv);
+                KWS_MFMA_A(acc_u[0], wgh[0][1][kc], hv);
+                KWS_MFMA_A(acc_r[1], wgh[1][0][kc], hv);
+                KWS_MFMA_A(acc_u[1], wgh[1][1][kc], hv);
             }
         }
-        f32x4 u[2];
+        mfma_fence(acc_r[0], acc_u[0], acc_r[1], acc_u[1]);
+        // ---- region A: the 16 sigmoids, hand-woven through the first half of frame t+1's gate x-part.
+        // Each bundle = one MFMA (matrix pipe, 32 cycles) + a slice of the VALU op list, pinned by
+        // sched_barrier so the issue order is the source order; the VALU slice runs in the MFMA's shadow.
+        float tr[8], tu[8];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f32x4 rh;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                rh[e] = sigmoid_f(acc_r[j][e]) * hreg[j][e];
-                u[j][e] = sigmoid_f(acc_u[j][e]);
-            }
-            rhbuf[(2 * w + j) * 64 + lane] = rh;
+        for (int e = 0; e < 8; ++e) {           // stage 0 reads the finished accumulators
+            tr[e] = acc_r[e >> 2][e & 3] * -kLog2e;
+            tu[e] = acc_u[e >> 2][e & 3] * -kLog2e;
         }
-        // frame t+1 gate x-part, first half: independent of the exchange, fills the barrier skew
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
-        gates_x_part(k_lo{}, k_mid{});
-        __syncthreads();      // #1: r(.)h visible; every wave is done reading hbuf
+        f32x4 u[2];
+        auto op_a = [&](auto ic) {              // op list: r stages 1-4 (32 ops), then u stages 1-3 (24)
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < 32) {
+                constexpr int st = i / 8, e = i % 8;
+                if constexpr (st == 0) tr[e] = __builtin_amdgcn_exp2f(tr[e]);
+                if constexpr (st == 1) tr[e] = 1.0f + tr[e];
+                if constexpr (st == 2) tr[e] = __builtin_amdgcn_rcpf(tr[e]);
+                if constexpr (st == 3) tr[e] = tr[e] * hreg[e >> 2][e & 3];
+                if constexpr (i == 31) {
+                    rhbuf[n0 * 64 + lane] = (f32x4){tr[0], tr[1], tr[2], tr[3]};
+                    rhbuf[n1 * 64 + lane] = (f32x4){tr[4], tr[5], tr[6], tr[7]};
+                }
+            } else if constexpr (i < 56) {
+                constexpr int st = (i - 32) / 8, e = i % 8;
+                if constexpr (st == 0) tu[e] = __builtin_amdgcn_exp2f(tu[e]);
+                if constexpr (st == 1) tu[e] = 1.0f + tu[e];
+                if constexpr (st == 2) u[e >> 2][e & 3] = __builtin_amdgcn_rcpf(tu[e]);
+            }
+        };
+        {
+            constexpr int NM = 4 * KSPLIT;                      // MFMAs available as cover
+            constexpr int VPER = (56 + NM - 1) / NM;
+            f32x4 ring[3];
+            ring[0] = wlds[(w * KCX + 0) * 64 + lane];
+            if (KSPLIT > 1) ring[1] = wlds[(w * KCX + 1) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, kc = m / 4, q = m % 4;
+                if constexpr (q == 0 && kc + 2 < KSPLIT) ring[(kc + 2) % 3] = wlds[(w * KCX + kc + 2) * 64 + lane];
+                const f32x4 a4 = ring[kc % 3];
+                if constexpr (q == 0) acc_r[0] = mfma4(a4.x, xcur[kc], acc_r[0]);
+                if constexpr (q == 1) acc_u[0] = mfma4(a4.y, xcur[kc], acc_u[0]);
+                if constexpr (q == 2) acc_r[1] = mfma4(a4.z, xcur[kc], acc_r[1]);
+                if constexpr (q == 3) acc_u[1] = mfma4(a4.w, xcur[kc], acc_u[1]);
+                static_for<m * VPER, (m + 1) * VPER>(op_a);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            static_for<NM * VPER, 56>(op_a);
+        }
+#ifdef KWS_TIMING
+        KWS_SYNC_T(0);
+#else
+        KWS_SYNC();           // #1: r(.)h visible; every wave is done reading hbuf
+#endif
         hb_a = rhbuf[0 * 64 + lane];
         hb_b = rhbuf[1 * 64 + lane];
-        gates_x_part(k_mid{}, k_hi{});     // second half hides the rhbuf read latency
+        gates_x_part(xcur, k_mid{}, k_hi{}, pinned{});     // second half hides the rhbuf read latency
 
         // candidate, h-part:  acc_c += Wc[I:,:]^T (r (.) h_{t-1})
 #pragma unroll
@@ -316,21 +454,57 @@ gru_layer_resident(const GruLayerParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kc = 4 * nn + e;
-                acc_c[0] = mfma4(wch[0][kc], rb[e], acc_c[0]);
-                acc_c[1] = mfma4(wch[1][kc], rb[e], acc_c[1]);
+                const float rv = rb[e];
+                KWS_MFMA_A(acc_c[0], wch[0][kc], rv);
+                KWS_MFMA_A(acc_c[1], wch[1][kc], rv);
             }
         }
+        mfma_fence(acc_c[0], acc_c[1]);
+        // ---- region B: tanh + state update, woven through most of frame t+1's candidate x-part
         const unsigned live = t < len_s ? 0xffffffffu : 0u;   // dynamic_rnn copy-through past seq_len
+        float tc[8], om[8], uh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tc[e] = acc_c[e >> 2][e & 3] * (2.0f * kLog2e);   // stage 0
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_c[j] = bias_c[j];
         f32x4 hout[2];
+        constexpr int NOPB = LAST ? 72 : 64;
+        auto op_b = [&](auto ic) {              // stage-major over the 8 owned elements
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < NOPB) {
+                constexpr int st = i / 8, e = i % 8, j = e >> 2, k = e & 3;
+                if constexpr (st == 0) tc[e] = __builtin_amdgcn_exp2f(tc[e]);           // e^{2x}
+                if constexpr (st == 1) tc[e] = 1.0f + tc[e];
+                if constexpr (st == 2) tc[e] = __builtin_amdgcn_rcpf(tc[e]);
+                if constexpr (st == 3) tc[e] = fmaf(-2.0f, tc[e], 1.0f);               // tanh
+                if constexpr (st == 4) om[e] = 1.0f - u[j][k];
+                if constexpr (st == 5) uh[e] = u[j][k] * hreg[j][k];
+                if constexpr (st == 6) tc[e] = fmaf(om[e], tc[e], uh[e]);               // u*h + (1-u)*c
+                if constexpr (st == 7) hreg[j][k] = bitsel(live, tc[e], hreg[j][k]);
+                if constexpr (st == 8) hout[j][k] = bitsel(live, tc[e], 0.f);
+            }
+        };
+        constexpr int NCX = 2 * KCX;                         // candidate x-part MFMAs of frame t+1
+        constexpr int NPOST = NCX >= 32 ? 16 : 8;            // kept for after barrier #2 (covers the hbuf read)
+        constexpr int NPRE = NCX - NPOST;
+        auto cand_x_mfma = [&](auto mc) {
+            constexpr int m = decltype(mc)::value, kc = m / 2;
+            if constexpr (m % 2 == 0) acc_c[0] = mfma4(wcx[0][kc], xcur[kc], acc_c[0]);
+            else acc_c[1] = mfma4(wcx[1][kc], xcur[kc], acc_c[1]);
+        };
+        {
+            constexpr int VPER = (NOPB + NPRE - 1) / NPRE;
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NPRE>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                cand_x_mfma(mc);
+                static_for<m * VPER, (m + 1) * VPER>(op_b);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            static_for<NPRE * VPER, NOPB>(op_b);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float c = tanh_f(acc_c[j][e]);
-                const float hn = u[j][e] * hreg[j][e] + (1.0f - u[j][e]) * c;
-                hreg[j][e] = bitsel(live, hn, hreg[j][e]);
-                hout[j][e] = bitsel(live, hn, 0.f);
-            }
             hbuf[(2 * w + j) * 64 + lane] = hreg[j];
             if (!LAST) {
                 const f32x4 o = hreg[j];
@@ -348,16 +522,52 @@ gru_layer_resident(const GruLayerParams p) {
             if (g < 2)
                 *reinterpret_cast<f32x4*>(stage + ((w * kFlushSteps + (t & (kFlushSteps - 1))) * 16 + s) * 8 + 4 * g) = accf;
         }
-        __syncthreads();      // #2: h_t visible; every wave is done reading rhbuf
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef KWS_TIMING
+        KWS_SYNC_T(1);
+#else
+        KWS_SYNC();           // #2: h_t visible; every wave is done reading rhbuf
+#endif
         hb_a = hbuf[0 * 64 + lane];
         hb_b = hbuf[1 * 64 + lane];
-        cand_x();             // frame t+1; hides the hbuf read latency
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NPRE, NCX>(cand_x_mfma);   // the rest of frame t+1's candidate x-part hides the hbuf read
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef KWS_ABL_NOFLUSH
         if (LAST && w == 0 && (((t + 1) & (kFlushSteps - 1)) == 0 || t == T - 1)) {
             const int t0 = t & ~(kFlushSteps - 1);
             flush_logits(p, stage, carry, group, t0, t - t0 + 1, lane, t == T - 1);
         }
+#endif
+    };
+
+    if (T > 0) {
+        load_x(xbuf0, 0);
+        if constexpr (FIRST) load_x(xbuf1, 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
+        gates_x_part(xbuf0, k_lo{}, k_hi{}, pinned{});
+        hb_a = hbuf[0 * 64 + lane];
+        hb_b = hbuf[1 * 64 + lane];
+        cand_x(xbuf0);
+    }
+    if constexpr (FIRST) {
+        // xbuf1 holds x(t+1) on even frames, xbuf0 on odd ones
+        for (int t = 0; t < T; t += 2) {
+            frame(t, xbuf1, xbuf0);
+            if (t + 1 < T) frame(t + 1, xbuf0, xbuf1);
+        }
+    } else {
+        for (int t = 0; t < T; ++t) frame(t, xbuf0, xbuf0);
     }
 
+#ifdef KWS_TIMING
+    if (p.dbg && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)group * 4 + w) * 8;
+        d[0] = seg_[0]; d[1] = wait_[0]; d[2] = seg_[1]; d[3] = wait_[1];
+        d[4] = __builtin_readcyclecounter() - tstart_; d[5] = T;
+    }
+#endif
     if (bvalid) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)

@@ -321,6 +321,12 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         p.B = B; p.T = T; p.I = Ld.in_dim; p.C = c.num_classes;
         p.KCX = resident ? Ld.kcx_res : Ld.kcx_gen;
 
+#ifdef KWS_TIMING
+        static unsigned long long* dbg_buf[8] = {nullptr};
+        const int groups_ = (B + 15) / 16;
+        if (!dbg_buf[l]) hipMalloc(reinterpret_cast<void**>(&dbg_buf[l]), (size_t)4096 * 4 * 8 * 8);
+        p.dbg = groups_ <= 4096 ? dbg_buf[l] : nullptr;
+#endif
         hipEvent_t ea = nullptr, eb = nullptr;
         if (h->profiling) {
             for (hipEvent_t* ev : {&ea, &eb}) {
@@ -336,6 +342,25 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             KWS_HIP(hipEventRecord(eb, st));
             h->pending.push_back({l, ea, eb});
         }
+#ifdef KWS_TIMING
+        {
+            static int dumped[8] = {0};
+            if (p.dbg && h->profiling && dumped[l]++ == 2) {
+                hipDeviceSynchronize();
+                std::vector<unsigned long long> hb((size_t)groups_ * 4 * 8);
+                hipMemcpy(hb.data(), p.dbg, hb.size() * 8, hipMemcpyDeviceToHost);
+                for (int gi : {0, 1, 100, 255}) {
+                    if (gi >= groups_) continue;
+                    for (int wv = 0; wv < 4; ++wv) {
+                        const unsigned long long* d = &hb[((size_t)gi * 4 + wv) * 8];
+                        const double T_ = (double)d[5];
+                        fprintf(stderr, "TIMING layer %d group %3d wave %d: per-frame cycles  seg1 %.0f wait1 %.0f seg2 %.0f wait2 %.0f total %.0f\n",
+                                l, gi, wv, d[0] / T_, d[1] / T_, d[2] / T_, d[3] / T_, d[4] / T_);
+                    }
+                }
+            }
+        }
+#endif
     }
     return KWS_OK;
 }

@@ -42,6 +42,7 @@ struct GruLayerParams {
     int use_relu;
     int B, T, I, C;
     int KCX;                // x-part k-chunks (generic: multiple of 4)
+    unsigned long long* dbg;  // timing-variant builds only (tools/build_variant.sh -DKWS_TIMING)
 };
 
 // launchers (gru_kernels.hip)
