@@ -59,6 +59,12 @@ __device__ __forceinline__ void lds_barrier() {
 #define KWS_TIMING_BAR() __builtin_amdgcn_s_barrier()
 #endif
 #if defined(KWS_TIMING)
+#define KWS_TS(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); \
+    fine_[i] += tn_ - tfine_; tfine_ = tn_; asm volatile("" ::: "memory"); } while (0)
+#else
+#define KWS_TS(i) do {} while (0)
+#endif
+#if defined(KWS_TIMING)
 // timing variant: s_memtime around each barrier (lgkmcnt is drained there anyway)
 #define KWS_SYNC_T(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long ta_ = __builtin_readcyclecounter(); \
     KWS_TIMING_BAR(); const unsigned long long tb_ = __builtin_readcyclecounter(); \
@@ -104,6 +110,33 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 constexpr float kLog2e = 1.4426950408889634f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Activations on register pairs.  Beside an f32 MFMA stream VALU work is not hidden (f32 MFMA and the
+// VALU share the FP32 datapath: tools/ubench/mfma_coissue.hip measures +2..3 cycles per plain op, +8 per
+// back-to-back transcendental and +14 for an isolated one), so the ops are clustered, packed
+// (v_pk_mul/add/fma_f32) and kept to the minimum count: sigmoid = pk_mul, 2 exp, pk_add, 2 rcp.
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
+    const f32x2 t = x * -kLog2e;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const f32x2 d = e + 1.0f;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return r;
+}
+__device__ __forceinline__ f32x2 tanh2(f32x2 x) {
+    const f32x2 t = x * (2.0f * kLog2e);
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const f32x2 d = e + 1.0f;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return r * -2.0f + 1.0f;
+}
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,12 +389,14 @@ gru_layer_resident(const GruLayerParams p) {
 #ifdef KWS_TIMING
     unsigned long long seg_[2] = {0, 0}, wait_[2] = {0, 0}, tlast_ = __builtin_readcyclecounter();
     const unsigned long long tstart_ = tlast_;
+    unsigned long long fine_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tfine_ = tlast_;
 #endif
     f32x4 hb_a, hb_b;            // exchange-read pipeline registers (two float4 in flight)
 
     // One frame.  xcur holds x(t+1) on entry (XD == 2) or receives it first (XD == 1, xcur == xnxt);
     // xnxt receives x(t+XD).
     auto frame = [&](int t, float (&xcur)[KCX], float (&xnxt)[KCX]) {
+        KWS_TS(0);            // [B2 .. here]: hb reads + post-barrier cand_x
         // gates, h-part:  acc_{r,u} += Wg[I:,:]^T h_{t-1}   (hb_a/hb_b were fetched behind cand_x);
         // one slice of x(t+XD) is requested per group
 #pragma unroll
@@ -383,57 +418,29 @@ gru_layer_resident(const GruLayerParams p) {
             }
         }
         mfma_fence(acc_r[0], acc_u[0], acc_r[1], acc_u[1]);
-        // ---- region A: the 16 sigmoids, hand-woven through the first half of frame t+1's gate x-part.
-        // Each bundle = one MFMA (matrix pipe, 32 cycles) + a slice of the VALU op list, pinned by
-        // sched_barrier so the issue order is the source order; the VALU slice runs in the MFMA's shadow.
-        float tr[8], tu[8];
+        KWS_TS(1);            // gates_h
+        // ---- region A: the 16 sigmoids as one VALU cluster (r first so r(.)h reaches LDS early), then the
+        // first half of frame t+1's gate x-part as cover for the exchange
+        f32x4 u[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {           // stage 0 reads the finished accumulators
-            tr[e] = acc_r[e >> 2][e & 3] * -kLog2e;
-            tu[e] = acc_u[e >> 2][e & 3] * -kLog2e;
+        for (int j = 0; j < 2; ++j) {
+            const f32x2 r_lo = sigmoid2((f32x2){acc_r[j][0], acc_r[j][1]});
+            const f32x2 r_hi = sigmoid2((f32x2){acc_r[j][2], acc_r[j][3]});
+            const f32x2 rh_lo = r_lo * (f32x2){hreg[j][0], hreg[j][1]};
+            const f32x2 rh_hi = r_hi * (f32x2){hreg[j][2], hreg[j][3]};
+            rhbuf[(2 * w + j) * 64 + lane] = (f32x4){rh_lo.x, rh_lo.y, rh_hi.x, rh_hi.y};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x2 u_lo = sigmoid2((f32x2){acc_u[j][0], acc_u[j][1]});
+            const f32x2 u_hi = sigmoid2((f32x2){acc_u[j][2], acc_u[j][3]});
+            u[j] = (f32x4){u_lo.x, u_lo.y, u_hi.x, u_hi.y};
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
-        f32x4 u[2];
-        auto op_a = [&](auto ic) {              // op list: r stages 1-4 (32 ops), then u stages 1-3 (24)
-            constexpr int i = decltype(ic)::value;
-            if constexpr (i < 32) {
-                constexpr int st = i / 8, e = i % 8;
-                if constexpr (st == 0) tr[e] = __builtin_amdgcn_exp2f(tr[e]);
-                if constexpr (st == 1) tr[e] = 1.0f + tr[e];
-                if constexpr (st == 2) tr[e] = __builtin_amdgcn_rcpf(tr[e]);
-                if constexpr (st == 3) tr[e] = tr[e] * hreg[e >> 2][e & 3];
-                if constexpr (i == 31) {
-                    rhbuf[n0 * 64 + lane] = (f32x4){tr[0], tr[1], tr[2], tr[3]};
-                    rhbuf[n1 * 64 + lane] = (f32x4){tr[4], tr[5], tr[6], tr[7]};
-                }
-            } else if constexpr (i < 56) {
-                constexpr int st = (i - 32) / 8, e = i % 8;
-                if constexpr (st == 0) tu[e] = __builtin_amdgcn_exp2f(tu[e]);
-                if constexpr (st == 1) tu[e] = 1.0f + tu[e];
-                if constexpr (st == 2) u[e >> 2][e & 3] = __builtin_amdgcn_rcpf(tu[e]);
-            }
-        };
-        {
-            constexpr int NM = 4 * KSPLIT;                      // MFMAs available as cover
-            constexpr int VPER = (56 + NM - 1) / NM;
-            f32x4 ring[3];
-            ring[0] = wlds[(w * KCX + 0) * 64 + lane];
-            if (KSPLIT > 1) ring[1] = wlds[(w * KCX + 1) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, NM>([&](auto mc) {
-                constexpr int m = decltype(mc)::value, kc = m / 4, q = m % 4;
-                if constexpr (q == 0 && kc + 2 < KSPLIT) ring[(kc + 2) % 3] = wlds[(w * KCX + kc + 2) * 64 + lane];
-                const f32x4 a4 = ring[kc % 3];
-                if constexpr (q == 0) acc_r[0] = mfma4(a4.x, xcur[kc], acc_r[0]);
-                if constexpr (q == 1) acc_u[0] = mfma4(a4.y, xcur[kc], acc_u[0]);
-                if constexpr (q == 2) acc_r[1] = mfma4(a4.z, xcur[kc], acc_r[1]);
-                if constexpr (q == 3) acc_u[1] = mfma4(a4.w, xcur[kc], acc_u[1]);
-                static_for<m * VPER, (m + 1) * VPER>(op_a);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            static_for<NM * VPER, 56>(op_a);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        gates_x_part(xcur, k_lo{}, k_mid{}, pinned{});
+        KWS_TS(2);            // region A
 #ifdef KWS_TIMING
         KWS_SYNC_T(0);
 #else
@@ -441,7 +448,9 @@ gru_layer_resident(const GruLayerParams p) {
 #endif
         hb_a = rhbuf[0 * 64 + lane];
         hb_b = rhbuf[1 * 64 + lane];
+        KWS_TS(3);            // barrier 1
         gates_x_part(xcur, k_mid{}, k_hi{}, pinned{});     // second half hides the rhbuf read latency
+        KWS_TS(4);            // gates_x second half
 
         // candidate, h-part:  acc_c += Wc[I:,:]^T (r (.) h_{t-1})
 #pragma unroll
@@ -460,30 +469,28 @@ gru_layer_resident(const GruLayerParams p) {
             }
         }
         mfma_fence(acc_c[0], acc_c[1]);
-        // ---- region B: tanh + state update, woven through most of frame t+1's candidate x-part
+        KWS_TS(5);            // cand_h
+        // ---- region B: tanh + state update as one VALU cluster
         const unsigned live = t < len_s ? 0xffffffffu : 0u;   // dynamic_rnn copy-through past seq_len
-        float tc[8], om[8], uh[8];
+        f32x4 hout[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) tc[e] = acc_c[e >> 2][e & 3] * (2.0f * kLog2e);   // stage 0
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f32x2 c = tanh2((f32x2){acc_c[j][2 * h2], acc_c[j][2 * h2 + 1]});
+                const f32x2 uu = {u[j][2 * h2], u[j][2 * h2 + 1]};
+                const f32x2 hh = {hreg[j][2 * h2], hreg[j][2 * h2 + 1]};
+                const f32x2 hn = (1.0f - uu) * c + uu * hh;       // u*h + (1-u)*c
+                hreg[j][2 * h2] = bitsel(live, hn.x, hh.x);
+                hreg[j][2 * h2 + 1] = bitsel(live, hn.y, hh.y);
+                if (LAST) {
+                    hout[j][2 * h2] = bitsel(live, hn.x, 0.f);
+                    hout[j][2 * h2 + 1] = bitsel(live, hn.y, 0.f);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc_c[j] = bias_c[j];
-        f32x4 hout[2];
-        constexpr int NOPB = LAST ? 72 : 64;
-        auto op_b = [&](auto ic) {              // stage-major over the 8 owned elements
-            constexpr int i = decltype(ic)::value;
-            if constexpr (i < NOPB) {
-                constexpr int st = i / 8, e = i % 8, j = e >> 2, k = e & 3;
-                if constexpr (st == 0) tc[e] = __builtin_amdgcn_exp2f(tc[e]);           // e^{2x}
-                if constexpr (st == 1) tc[e] = 1.0f + tc[e];
-                if constexpr (st == 2) tc[e] = __builtin_amdgcn_rcpf(tc[e]);
-                if constexpr (st == 3) tc[e] = fmaf(-2.0f, tc[e], 1.0f);               // tanh
-                if constexpr (st == 4) om[e] = 1.0f - u[j][k];
-                if constexpr (st == 5) uh[e] = u[j][k] * hreg[j][k];
-                if constexpr (st == 6) tc[e] = fmaf(om[e], tc[e], uh[e]);               // u*h + (1-u)*c
-                if constexpr (st == 7) hreg[j][k] = bitsel(live, tc[e], hreg[j][k]);
-                if constexpr (st == 8) hout[j][k] = bitsel(live, tc[e], 0.f);
-            }
-        };
         constexpr int NCX = 2 * KCX;                         // candidate x-part MFMAs of frame t+1
         constexpr int NPOST = NCX >= 32 ? 16 : 8;            // kept for after barrier #2 (covers the hbuf read)
         constexpr int NPRE = NCX - NPOST;
@@ -492,17 +499,6 @@ gru_layer_resident(const GruLayerParams p) {
             if constexpr (m % 2 == 0) acc_c[0] = mfma4(wcx[0][kc], xcur[kc], acc_c[0]);
             else acc_c[1] = mfma4(wcx[1][kc], xcur[kc], acc_c[1]);
         };
-        {
-            constexpr int VPER = (NOPB + NPRE - 1) / NPRE;
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, NPRE>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                cand_x_mfma(mc);
-                static_for<m * VPER, (m + 1) * VPER>(op_b);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            static_for<NPRE * VPER, NOPB>(op_b);
-        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             hbuf[(2 * w + j) * 64 + lane] = hreg[j];
@@ -523,6 +519,9 @@ gru_layer_resident(const GruLayerParams p) {
                 *reinterpret_cast<f32x4*>(stage + ((w * kFlushSteps + (t & (kFlushSteps - 1))) * 16 + s) * 8 + 4 * g) = accf;
         }
         __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NPRE>(cand_x_mfma);     // most of frame t+1's candidate x-part covers the LDS write
+        __builtin_amdgcn_sched_barrier(0);
+        KWS_TS(6);            // region B + writes + fc
 #ifdef KWS_TIMING
         KWS_SYNC_T(1);
 #else
@@ -566,6 +565,8 @@ gru_layer_resident(const GruLayerParams p) {
         unsigned long long* d = p.dbg + ((size_t)group * 4 + w) * 8;
         d[0] = seg_[0]; d[1] = wait_[0]; d[2] = seg_[1]; d[3] = wait_[1];
         d[4] = __builtin_readcyclecounter() - tstart_; d[5] = T;
+        unsigned long long* f = p.dbg + (size_t)4096 * 4 * 8 + ((size_t)group * 4 + w) * 8;
+        for (int i = 0; i < 8; ++i) f[i] = fine_[i];
     }
 #endif
     if (bvalid) {

@@ -324,7 +324,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
 #ifdef KWS_TIMING
         static unsigned long long* dbg_buf[8] = {nullptr};
         const int groups_ = (B + 15) / 16;
-        if (!dbg_buf[l]) hipMalloc(reinterpret_cast<void**>(&dbg_buf[l]), (size_t)4096 * 4 * 8 * 8);
+        if (!dbg_buf[l]) hipMalloc(reinterpret_cast<void**>(&dbg_buf[l]), (size_t)4096 * 4 * 8 * 8 * 2);
         p.dbg = groups_ <= 4096 ? dbg_buf[l] : nullptr;
 #endif
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -347,7 +347,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             static int dumped[8] = {0};
             if (p.dbg && h->profiling && dumped[l]++ == 2) {
                 hipDeviceSynchronize();
-                std::vector<unsigned long long> hb((size_t)groups_ * 4 * 8);
+                std::vector<unsigned long long> hb((size_t)4096 * 4 * 8 * 2);
                 hipMemcpy(hb.data(), p.dbg, hb.size() * 8, hipMemcpyDeviceToHost);
                 for (int gi : {0, 1, 100, 255}) {
                     if (gi >= groups_) continue;
@@ -356,6 +356,9 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
                         const double T_ = (double)d[5];
                         fprintf(stderr, "TIMING layer %d group %3d wave %d: per-frame cycles  seg1 %.0f wait1 %.0f seg2 %.0f wait2 %.0f total %.0f\n",
                                 l, gi, wv, d[0] / T_, d[1] / T_, d[2] / T_, d[3] / T_, d[4] / T_);
+                        const unsigned long long* f = &hb[(size_t)4096 * 4 * 8 + ((size_t)gi * 4 + wv) * 8];
+                        fprintf(stderr, "  FINE post-B2 %.0f | gates_h %.0f | regionA %.0f | B1 %.0f | gx2 %.0f | cand_h %.0f | regionB %.0f\n",
+                                f[0] / T_, f[1] / T_, f[2] / T_, f[3] / T_, f[4] / T_, f[5] / T_, f[6] / T_);
                     }
                 }
             }
