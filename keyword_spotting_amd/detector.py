@@ -1,0 +1,123 @@
+"""HotwordDetector -- the streaming state-carry loop of detector.py:104-316 without the audio I/O
+(pyaudio capture, wav dumps and matplotlib plots are host I/O with no arithmetic and are out of scope).
+
+What is reproduced, per sess.run-sized chunk and per stream:
+  * zero-initialised recurrent state owned by the caller of the model (detector.py:123-124)
+  * VAD gate: a silent chunk resets the state and clears the decode window BEFORE the chunk is run
+    (detector.py:168-177; vad(data, 30))
+  * model run with the carried state, state replaced by the returned one (detector.py:190-196)
+  * 15-chunk sliding window of softmax chunks (SimpleQueue(15), detector.py:122,195,197)
+  * ctc_decode2 over the whole concatenated window, ctc_predict(result, '1233') (detector.py:200-201)
+  * on trigger: callback, window cleared, state reset (detector.py:202-209)
+  * sample carry arithmetic between PCM chunks (detector.py:179-183) -- ChunkFramer
+  * test2: chunked replay of a whole utterance, one ctc_decode at the end (detector.py:254-289)
+
+B independent streams run in lock step (one kws_step per chunk for all of them); the window
+bookkeeping is per stream.  Input is the mel variant of the graph (models/rnn_ctc.py:150-153); the
+PCM front-end is SURVEY 8f next-row 1.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .basic_vad import vad as _vad
+from .prediction import decode_batch
+from .prediction import ctc_predict as _ctc_predict
+from .queue import SimpleQueue
+
+
+class ChunkFramer(object):
+    """Sample bookkeeping of detector.py:179-183: how many frames a PCM chunk yields once the carried
+    tail of the previous chunk is prepended, and how many samples are carried forward."""
+
+    def __init__(self, fft_size=400, hop_size=160):
+        self.fft_size, self.hop_size = fft_size, hop_size
+        self.carry = 0
+
+    def push(self, n_samples):
+        total = self.carry + n_samples
+        frames = 0 if total < self.fft_size else (total - self.fft_size) // self.hop_size + 1
+        self.carry = (total - self.fft_size) % self.hop_size + (self.fft_size - self.hop_size)
+        return frames
+
+
+class HotwordDetector(object):
+    def __init__(self, model, batch=1, window_chunks=15, vad_thres=30, label=None, decode_thres=0.4,
+                 detected_callback=None):
+        self.model = model
+        self.config = model.config
+        self.batch = int(batch)
+        self.vad_thres = vad_thres
+        self.label = label or self.config.label_seqs
+        self.decode_thres = decode_thres
+        self.detected_callback = detected_callback
+        self.prob_queue = [SimpleQueue(window_chunks) for _ in range(self.batch)]
+        self.state = model.zero_state(self.batch)
+        self.reset_next = torch.zeros(self.batch, dtype=torch.uint8, device=model.device)
+        self.triggers = [0] * self.batch
+
+    # detector.py:313-316 -- on the device the reset is a per-stream mask consumed by the next kws_step
+    def clean_state(self, which=None):
+        if which is None:
+            self.reset_next.fill_(1)
+        else:
+            self.reset_next[which] = 1
+
+    def feed(self, mel_chunk, pcm_chunk=None, speech=None):
+        """One loop iteration of detector.py:158-209 for every stream.
+        mel_chunk [B,T,n_mel] (or [T,n_mel] when batch == 1).  The VAD decision comes from `speech`
+        ([B] bool) or is computed from `pcm_chunk` ([B,N]) with vad(data, vad_thres); neither -> speech.
+        Returns the list of streams that triggered on this chunk."""
+        mel = torch.as_tensor(mel_chunk)
+        if mel.dim() == 2:
+            mel = mel.unsqueeze(0)
+        if mel.shape[0] != self.batch:
+            raise _lib.InvalidArgumentError(-1, "expected %d streams, got %d" % (self.batch, mel.shape[0]))
+        if speech is None and pcm_chunk is not None:
+            pcm = torch.as_tensor(pcm_chunk)
+            speech = _vad(pcm if pcm.dim() == 2 else pcm.unsqueeze(0), self.vad_thres).bool().cpu().numpy()
+        if speech is not None:
+            for b in np.nonzero(~np.asarray(speech, bool))[0]:       # :171-177
+                self.clean_state(int(b))
+                self.prob_queue[int(b)].clear()
+        r = self.model.forward(mel, self.state, reset_mask=self.reset_next, want_logits=False, want_softmax=True,
+                               state_out=self.state)
+        self.reset_next.zero_()
+        softmax = r["softmax"]
+        for b in range(self.batch):                                  # :195
+            self.prob_queue[b].add(softmax[b])
+        windows = [torch.cat(q.get_all(), 0) for q in self.prob_queue]   # :197
+        lens = torch.tensor([w.shape[0] for w in windows], dtype=torch.int32)
+        tmax = int(lens.max()) if self.batch else 0
+        padded = torch.zeros(self.batch, max(tmax, 1), self.config.num_classes, device=self.model.device)
+        for b, w in enumerate(windows):
+            padded[b, :w.shape[0]] = w
+        words, counts = decode_batch(_lib.DECODE2, padded, lens, 3, self.decode_thres, 0.0)   # :200
+        hits = _ctc_predict((words, counts), self.label).cpu().numpy()                        # :201
+        fired = []
+        for b in np.nonzero(hits)[0]:
+            b = int(b)
+            fired.append(b)
+            self.triggers[b] += 1
+            if self.detected_callback is not None:
+                self.detected_callback(b)
+            self.prob_queue[b].clear()                               # :203
+            self.clean_state(b)                                      # :208
+        return fired
+
+    def test2(self, mel, chunk_frames):
+        """detector.py:254-289: replay whole utterances [B,T,n_mel] in chunks with the state threaded
+        through, accumulate the softmax, decode once with ctc_decode.  Returns (words, counts)."""
+        mel = torch.as_tensor(mel)
+        if mel.dim() == 2:
+            mel = mel.unsqueeze(0)
+        mel = mel.to(self.model.device)
+        state = self.model.zero_state(mel.shape[0])                  # :263
+        parts, pos = [], 0
+        for n in chunk_frames:
+            r = self.model.forward(mel[:, pos:pos + n].contiguous(), state, want_logits=False, want_softmax=True)
+            state = r["state"]                                       # :284
+            parts.append(r["softmax"])                               # :285
+            pos += n
+        accu = torch.cat(parts, 1)
+        return decode_batch(_lib.DECODE, accu, None, 3, 0.5, 0.2)    # :288

@@ -1,0 +1,109 @@
+"""State-carry loop (detector.py:148-212, :254-289) against a pure-oracle replay of the same policy."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_oracle as D
+from oracle import gru_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _keyword_weights(seed=0):
+    """Random GRU + an fc layer scaled up so that words fire often (random weights rarely spell 1233)."""
+    w = G.init_weights(seed=seed)
+    w["Wfc"] = (w["Wfc"] * 3.0).astype(np.float32)
+    return w
+
+
+def _oracle_loop(w, mel, chunks, speech, label, window=15, thres=0.4):
+    """The reference policy replayed with the oracle, one stream: returns the chunk indices that fire."""
+    state = np.zeros((2, 1, 128), np.float64)
+    queue, fired, pos = D.SimpleQueue(window), [], 0
+    margins_ok = True
+    for ci, n in enumerate(chunks):
+        if not speech[ci]:
+            state[:] = 0
+            queue.clear()
+        lg, state = G.gru_forward(w, mel[None, pos:pos + n], state, dtype=np.float64)
+        sm = G.softmax(lg)[0]
+        p = np.sort(sm[:, 1:5], axis=1)
+        margins_ok &= bool((np.abs(p[:, -1] - thres) > 1e-4).all() and (p[:, -1] - p[:, -2] > 1e-4).all())
+        queue.add(sm)
+        window_sm = np.concatenate(queue.get_all(), 0)
+        if D.ctc_predict(D.ctc_decode2(window_sm, 6, thres), label):
+            fired.append(ci)
+            queue.clear()
+            state[:] = 0
+        pos += n
+    return fired, margins_ok
+
+
+def test_detector_loop_matches_oracle_policy():
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.detector import HotwordDetector
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    w = _keyword_weights()
+    b = 6
+    chunks = D.chunk_frame_counts([3600] * 40)               # 21,22,23,22,... frames (detector.py:119,181-183)
+    mel = G.synthetic_mel(b, sum(chunks), 40, seed=91)
+    rng = np.random.default_rng(92)
+    speech = rng.random((len(chunks), b)) > 0.1               # occasional silent chunk -> reset
+    model = DeployModel(get_config(), w)
+    label = "12"                                              # short label so triggers happen on random weights
+    det = HotwordDetector(model, batch=b, label=label)
+    got = [[] for _ in range(b)]
+    pos = 0
+    for ci, n in enumerate(chunks):
+        for s in det.feed(torch.from_numpy(mel[:, pos:pos + n].copy()), speech=speech[ci]):
+            got[s].append(ci)
+        pos += n
+    total, checked = 0, 0
+    for s in range(b):
+        want, ok = _oracle_loop(w, mel[s], chunks, speech[:, s], label)
+        if ok:                                               # no frame within 1e-4 of a threshold/tie
+            assert got[s] == want, (s, got[s], want)
+            checked += 1
+            total += len(want)
+    assert checked >= 3 and total >= 3                        # the policy (trigger + reset + window) was exercised
+
+
+def test_vad_from_pcm_drives_reset():
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.detector import HotwordDetector
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    w = _keyword_weights()
+    model = DeployModel(get_config(), w)
+    det = HotwordDetector(model, batch=2, label="1233")
+    mel = torch.from_numpy(G.synthetic_mel(2, 22, 40, seed=93))
+    loud = torch.full((2, 3600), 0.05)                        # sum|x| = 180 > 30
+    det.feed(mel, pcm_chunk=loud)
+    assert det.state.abs().sum() > 0 and all(len(q.get_all()) == 1 for q in det.prob_queue)
+    quiet = loud.clone()
+    quiet[1] = 0.001                                          # stream 1: sum|x| = 3.6 < 30 -> reset before the run
+    det.feed(mel, pcm_chunk=quiet)
+    assert len(det.prob_queue[0].get_all()) == 2 and len(det.prob_queue[1].get_all()) == 1
+    want, _ = G.gru_forward(w, mel.numpy()[1:2], dtype=np.float64)     # stream 1 restarted from zero state
+    got = det.prob_queue[1].get_all()[0].cpu().numpy()
+    assert np.abs(got - G.softmax(want)[0]).max() < 2e-5
+
+
+def test_test2_chunked_replay():
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.detector import ChunkFramer, HotwordDetector
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    w = _keyword_weights(seed=3)
+    model = DeployModel(get_config(), w)
+    fr = ChunkFramer()
+    chunks = [fr.push(3600) for _ in range(13)]
+    assert chunks == D.chunk_frame_counts([3600] * 13)
+    mel = G.synthetic_mel(3, sum(chunks), 40, seed=94)
+    det = HotwordDetector(model, batch=3)
+    words, counts = det.test2(torch.from_numpy(mel), chunks)
+    want_l, _ = G.gru_forward(w, mel, dtype=np.float64)
+    sm = G.softmax(want_l)
+    for s in range(3):
+        p = np.sort(sm[s][:, 1:5], axis=1)
+        if (np.abs(p[:, -1] - 0.5) > 1e-4).all() and (np.abs(p[:, -1] - 0.2) > 1e-4).all() and \
+                (np.abs(sm[s][:, 3] - 0.2) > 1e-4).all() and (np.abs(p[:, -1] - 0.6) > 1e-4).all():
+            np.testing.assert_array_equal(words[s, :counts[s]].cpu().numpy(), D.ctc_decode(sm[s])[1::2])

@@ -68,3 +68,14 @@ def test_shard_bounds_partition():
     assert shard_seed(1, 5) == 6
     with pytest.raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+def test_chunk_framer_matches_reference_arithmetic():
+    """detector.py:179-183 sample carry: pinned by hand-derived counts and by the oracle restatement."""
+    from keyword_spotting_amd.detector import ChunkFramer
+    from oracle import decode_oracle as D
+    fr = ChunkFramer()
+    assert [fr.push(3600) for _ in range(9)] == [21, 22, 23, 22, 23, 22, 23, 22, 23]
+    for sizes in ([3600] * 20, [1234, 4000, 800, 160, 159, 4001], [400], [399, 1]):
+        fr = ChunkFramer()
+        assert [fr.push(n) for n in sizes] == D.chunk_frame_counts(sizes)
