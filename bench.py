@@ -27,7 +27,22 @@ PEAK_FP32_TFLOPS = 157.3                                                      # 
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(cfg, w, seconds_budget=8.0):
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
+    (profiles/r*_pmc.json, written by tools/prof.sh on the same bench command; FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE).  None when no profile has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for k, c in data.items():
+        if kernel_substr in k and "hbm_bytes_per_launch" in c:
+            return c["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
+def cpu_baseline(cfg, w, seconds_budget=10.0):
     """The oracle timed on this host (reference TF-1.x is not executable here or on the GPU box):
     (ii) tight C restatement, 1 core and all cores; (i) torch-CPU eager op-by-op = 'TF-CPU stand-in'.
     Workload = BASELINE config 1: batch 1, 300 frames, state round trip, greedy decode."""
@@ -59,8 +74,8 @@ def cpu_baseline(cfg, w, seconds_budget=8.0):
         run_c(mel1, st1, 1)
         n += 1
     c1 = n * 300 / (time.perf_counter() - t0)
-    meln = G.synthetic_mel(cores * 4, 300, cfg.n_mel, seed=2)
-    stn = np.zeros((cfg.num_layers, cores * 4, cfg.hidden_size), np.float32)
+    meln = G.synthetic_mel(cores * 8, 300, cfg.n_mel, seed=2)
+    stn = np.zeros((cfg.num_layers, cores * 8, cfg.hidden_size), np.float32)
     run_c(meln, stn, cores)
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds_budget / 4:
@@ -154,6 +169,8 @@ def main():
         dom_ms = ktimes[dom][0] / max(ktimes[dom][1], 1)
         achieved = FLOP_PER_FRAME["layer"][dom] * B * T / (dom_ms * 1e-3) / 1e12
         all_ms = sum(k[0] / max(k[1], 1) for k in ktimes)
+        dom_name = "gru_layer_resident<%s>" % ("10, true, false" if dom == 0 else "32, false, true")
+        traffic, traffic_src = pmc_traffic(dom_name) if model.kernel != "generic" else (None, None)
         line = {
             "metric": "mel-frames/s (real-time 10 ms-hop audio streams sustained = value/100)",
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +182,8 @@ def main():
                        "kernel": model.kernel},
             "realtime_streams": value / 100.0,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": (512 + 49 if dom else 160 + 512) * B * T,
                          "kernel": "gru_layer_%s layer %d" % ("resident" if model.kernel != "generic" else "generic", dom),
                          "kernel_ms": dom_ms, "launches": ktimes[dom][1],
                          "all_layers_tflops": FLOP_PER_FRAME["total"] * B * T / (all_ms * 1e-3) / 1e12,

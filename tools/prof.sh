@@ -16,3 +16,9 @@ for PMC in "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY S
 done
 python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# the pieces that get committed under profiles/ (copied there by the builder)
+mkdir -p $OUT/commit
+cp $OUT/summary.txt $OUT/commit/${TAG}_rocprofv3_summary.txt
+cp $OUT/pmc.json $OUT/commit/${TAG}_pmc.json
+cp $OUT/trace/*kernel_stats.csv $OUT/commit/${TAG}_kernel_stats.csv 2>/dev/null
+tail -1 $OUT/trace_bench.log > $OUT/commit/${TAG}_bench_under_trace.json
