@@ -330,6 +330,9 @@ gru_layer_resident(const GruLayerParams p) {
     // group: a burst of 10 divergent loads issued by four phase-locked waves at once backs up the
     // address path and, issue being in order, stalls the MFMAs queued behind it (~900 cycles/frame).
     auto load_x_slice = [&](float (&dst)[KCX], int t_req, const int sl) {   // sl: unrolled constant
+#ifdef KWS_ABL_NOXLOAD
+        return;
+#endif
         const int t = t_req < T ? t_req : T - 1;
         if constexpr (FIRST) {
 #pragma unroll
@@ -402,9 +405,11 @@ gru_layer_resident(const GruLayerParams p) {
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const f32x4 hb = (nn & 1) ? hb_b : hb_a;
+#ifndef KWS_ABL_NOLDSB
             if (nn + 2 < NT) {
                 if (nn & 1) hb_b = hbuf[(nn + 2) * 64 + lane]; else hb_a = hbuf[(nn + 2) * 64 + lane];
             }
+#endif
             load_x_slice(xnxt, t + XD, nn);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -453,22 +458,38 @@ gru_layer_resident(const GruLayerParams p) {
         KWS_TS(4);            // gates_x second half
 
         // candidate, h-part:  acc_c += Wc[I:,:]^T (r (.) h_{t-1})
+#ifdef KWS_EXP_CAND4
+        f32x4 acc_c2[2] = {splat4(0.f), splat4(0.f)};
+#endif
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const f32x4 rb = (nn & 1) ? hb_b : hb_a;
+#ifndef KWS_ABL_NOLDSB
             if (nn + 2 < NT) {
                 if (nn & 1) hb_b = rhbuf[(nn + 2) * 64 + lane]; else hb_a = rhbuf[(nn + 2) * 64 + lane];
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kc = 4 * nn + e;
                 const float rv = rb[e];
+#ifdef KWS_EXP_CAND4
+                if (e & 1) { KWS_MFMA_A(acc_c2[0], wch[0][kc], rv); KWS_MFMA_A(acc_c2[1], wch[1][kc], rv); }
+                else { KWS_MFMA_A(acc_c[0], wch[0][kc], rv); KWS_MFMA_A(acc_c[1], wch[1][kc], rv); }
+#else
                 KWS_MFMA_A(acc_c[0], wch[0][kc], rv);
                 KWS_MFMA_A(acc_c[1], wch[1][kc], rv);
+#endif
             }
         }
+#ifdef KWS_EXP_CAND4
+        mfma_fence(acc_c[0], acc_c[1], acc_c2[0], acc_c2[1]);
+        acc_c[0] += acc_c2[0];
+        acc_c[1] += acc_c2[1];
+#else
         mfma_fence(acc_c[0], acc_c[1]);
+#endif
         KWS_TS(5);            // cand_h
         // ---- region B: tanh + state update as one VALU cluster
         const unsigned live = t < len_s ? 0xffffffffu : 0u;   // dynamic_rnn copy-through past seq_len
