@@ -248,20 +248,60 @@ gru_layer_resident(const GruLayerParams p) {
     int* carry = reinterpret_cast<int*>(stage + 4 * kFlushSteps * 16 * 8);  // LAST: [16]
 
     // ---- stage weights: registers (recurrent + candidate) and LDS (gate x-part) ------------------
+    // p.wh is the group-of-4 layout [NT][3][KCH/4][64][4]: one dwordx4 per four fragments.  p.wx is the
+    // same layout above the first layer and fragment-major [NT][3][KCX][64] (interleaved k map) in it.
     float wgh[2][2][KCH];   // [tile][r|u][k-chunk]  A fragments of Wg rows I..I+H
     float wch[2][KCH];      // candidate, h-part
     float wcx[2][KCX];      // candidate, x-part
+    const f32x4* wh4 = reinterpret_cast<const f32x4*>(p.wh);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = 2 * w + j;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int k4 = 0; k4 < KCH / 4; ++k4) {
+            const f32x4 vr = wh4[((n * 3 + 0) * (KCH / 4) + k4) * 64 + lane];
+            const f32x4 vu = wh4[((n * 3 + 1) * (KCH / 4) + k4) * 64 + lane];
+            const f32x4 vc = wh4[((n * 3 + 2) * (KCH / 4) + k4) * 64 + lane];
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) wgh[j][q][kc] = p.wh[((n * 3 + q) * KCH + kc) * 64 + lane];
+            for (int e = 0; e < 4; ++e) {
+                wgh[j][0][4 * k4 + e] = vr[e];
+                wgh[j][1][4 * k4 + e] = vu[e];
+                wch[j][4 * k4 + e] = vc[e];
+            }
+        }
+    }
+    if constexpr (FIRST) {
 #pragma unroll
-        for (int kc = 0; kc < KCH; ++kc) wch[j][kc] = p.wh[((n * 3 + 2) * KCH + kc) * 64 + lane];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kc = 0; kc < KCX; ++kc) wcx[j][kc] = p.wx[((n * 3 + 2) * KCX + kc) * 64 + lane];
+            for (int kc = 0; kc < KCX; ++kc) wcx[j][kc] = p.wx[(((2 * w + j) * 3 + 2) * KCX + kc) * 64 + lane];
+        for (int kc = 0; kc < KCX; ++kc) {
+            f32x4 v;
+            v.x = p.wx[((n0 * 3 + 0) * KCX + kc) * 64 + lane];
+            v.y = p.wx[((n0 * 3 + 1) * KCX + kc) * 64 + lane];
+            v.z = p.wx[((n1 * 3 + 0) * KCX + kc) * 64 + lane];
+            v.w = p.wx[((n1 * 3 + 1) * KCX + kc) * 64 + lane];
+            wlds[(w * KCX + kc) * 64 + lane] = v;
+        }
+    } else {
+        const f32x4* wx4 = reinterpret_cast<const f32x4*>(p.wx);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k4 = 0; k4 < KCX / 4; ++k4) {
+                const f32x4 vc = wx4[(((2 * w + j) * 3 + 2) * (KCX / 4) + k4) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wcx[j][4 * k4 + e] = vc[e];
+            }
+        for (int k4 = 0; k4 < KCX / 4; ++k4) {
+            const f32x4 r0 = wx4[((n0 * 3 + 0) * (KCX / 4) + k4) * 64 + lane];
+            const f32x4 u0 = wx4[((n0 * 3 + 1) * (KCX / 4) + k4) * 64 + lane];
+            const f32x4 r1 = wx4[((n1 * 3 + 0) * (KCX / 4) + k4) * 64 + lane];
+            const f32x4 u1 = wx4[((n1 * 3 + 1) * (KCX / 4) + k4) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                wlds[(w * KCX + 4 * k4 + e) * 64 + lane] = (f32x4){r0[e], u0[e], r1[e], u1[e]};
+        }
     }
     // park the recurrent fragments in AGPRs for the whole launch (192 of the 256)
 #pragma unroll
@@ -274,14 +314,6 @@ gru_layer_resident(const GruLayerParams p) {
         }
     }
     asm volatile("s_nop 7" ::: "memory");   // v_accvgpr_write -> MFMA SrcA distance
-    for (int kc = 0; kc < KCX; ++kc) {
-        f32x4 v;
-        v.x = p.wx[((n0 * 3 + 0) * KCX + kc) * 64 + lane];
-        v.y = p.wx[((n0 * 3 + 1) * KCX + kc) * 64 + lane];
-        v.z = p.wx[((n1 * 3 + 0) * KCX + kc) * 64 + lane];
-        v.w = p.wx[((n1 * 3 + 1) * KCX + kc) * 64 + lane];
-        wlds[(w * KCX + kc) * 64 + lane] = v;
-    }
     f32x4 bias_r[2], bias_u[2], bias_c[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -784,9 +816,13 @@ bool gru_resident_supported(int hidden, int in_dim, bool first) {
 
 template <typename K>
 static hipError_t launch_with_lds(K kernel, const GruLayerParams& p, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static size_t granted = 0;           // per kernel instantiation (one static per template instance)
+    if (lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted = lds;
+    }
     const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
     hipLaunchKernelGGL(kernel, dim3(groups), dim3(256), lds, st, p);
     return hipGetLastError();

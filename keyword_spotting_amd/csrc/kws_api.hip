@@ -299,8 +299,10 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
                               (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok);
         kws::GruLayerParams p;
         memset(&p, 0, sizeof(p));
-        p.wx = h->d_weights + (resident ? Ld.wx_res : Ld.wx_gen);
-        p.wh = h->d_weights + (resident ? Ld.wh_res : Ld.wh_gen);
+        // resident kernels read the group-of-4 layouts too (dwordx4 prologue), except the first layer's
+        // x-part, whose k map is the interleaved one
+        p.wx = h->d_weights + ((resident && first) ? Ld.wx_res : Ld.wx_gen);
+        p.wh = h->d_weights + Ld.wh_gen;
         p.bias = h->d_weights + Ld.bias;
         p.wfc = h->d_weights + h->wfc_off;
         p.bfc = h->d_weights + h->bfc_off;

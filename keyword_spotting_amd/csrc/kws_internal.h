@@ -19,8 +19,8 @@ constexpr int kMaxClasses = 8;
 // k-chunks 4n..4n+3 -- so hidden state never needs a cross-lane transpose.
 struct GruLayerParams {
     // weights (device, packed by pack.cpp)
-    const float* wx;        // x-part fragments  resident: [NT][3][KCX][64]   generic: [NT][3][KCX4][64][4]
-    const float* wh;        // h-part fragments  resident: [NT][3][KCH][64]   generic: [NT][3][NT][64][4]
+    const float* wx;        // x-part fragments  [NT][3][KCX/4][64][4]; resident first layer: [NT][3][KCX][64]
+    const float* wh;        // h-part fragments  [NT][3][H/16][64][4]
     const float* bias;      // [3][H]  (r, u, c)
     const float* wfc;       // LAST: [H/4][64] fragments of Wfc^T padded to 16 rows
     const float* bfc;       // LAST: [16] padded
