@@ -45,14 +45,6 @@ __device__ __forceinline__ float tanh_f(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
 #endif
 }
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every frame
-// would then wait for the inter-layer scratch stores and for the x prefetch of the next frame, which
-// no other wave of the group ever reads.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 #if defined(KWS_TIMING) && defined(KWS_ABL_NOBARRIER)
 #define KWS_TIMING_BAR() do {} while (0)
 #else
@@ -139,27 +131,62 @@ __device__ __forceinline__ f32x2 tanh2(f32x2 x) {
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every frame
+// would then wait for the inter-layer scratch stores and for the x prefetch of the next frame, which
+// no other wave of the group ever reads.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 // ------------------------------------------------------------------------------------------------
-// Last-layer epilogue: sums the four waves' partial logits staged in LDS, applies relu/clip,
-// softmax and ctc_decode2's frame rule, and writes [B,T,C] rows.  Executed by wave 0 only:
-// lane = 4*stream + frame-in-block, so the previous frame's word is one __shfl_up away.
-//   stage: [4 waves][kFlushSteps][16 streams][8]   carry: [16] previous word per stream
+// Last-layer epilogue.  Each wave leaves the partial logits of its 32 units in `pstage`; after the
+// frame's second barrier ONE wave (rotating, w == t & 3) folds the four partials into a 16-frame ring.
+// Every kRingFrames frames (and at the end of the call) ALL FOUR waves flush: wave w takes frames
+// 4w..4w+3 of the block x 16 streams = 64 items, so the softmax / decode / store work is spread
+// over the whole group instead of stalling three waves behind one.
+//   pstage [4 waves][16 streams][8]     lring [16 frames][16 streams][8]
+//   words  [16 frames][16 streams]      carry [2][16]   (previous block's last word, ping-pong)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void flush_logits(const GruLayerParams& p, const float* stage, int* carry,
-                                             int group, int t0, int n, int lane, bool final_flush) {
-    const int tt = lane & (kFlushSteps - 1);
+constexpr int kRingFrames = 16;
+struct EpilogueLds {
+    float* pstage;
+    float* lring;
+    int* words;
+    int* carry;
+};
+constexpr size_t kEpilogueLdsBytes = (4 * 16 * 8 + kRingFrames * 16 * 8) * 4 + kRingFrames * 16 * 4 + 2 * 16 * 4;
+__device__ __forceinline__ EpilogueLds epilogue_carve(char* base) {
+    EpilogueLds e;
+    e.pstage = reinterpret_cast<float*>(base);
+    e.lring = e.pstage + 4 * 16 * 8;
+    e.words = reinterpret_cast<int*>(e.lring + kRingFrames * 16 * 8);
+    e.carry = e.words + kRingFrames * 16;
+    return e;
+}
+
+// fold the 4 partial logit vectors of frame t into the ring: 32 lanes, (stream, half) each
+__device__ __forceinline__ void epilogue_fold(const EpilogueLds& e, int t, int lane) {
+    if (lane < 32) {
+        const int s = lane >> 1, half = lane & 1;
+        f32x4 v = *reinterpret_cast<const f32x4*>(e.pstage + (0 * 16 + s) * 8 + 4 * half);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(e.pstage + (w * 16 + s) * 8 + 4 * half);
+        *reinterpret_cast<f32x4*>(e.lring + (((t & (kRingFrames - 1)) * 16 + s) * 8 + 4 * half)) = v;
+    }
+}
+
+// flush frames [t0, t0+n) of the ring; called by all four waves of the group together
+__device__ __forceinline__ void epilogue_flush(const GruLayerParams& p, const EpilogueLds& e, int group, int t0,
+                                               int n, int w, int lane, bool final_flush) {
+    const int f = 4 * w + (lane & 3);          // frame within the block
     const int s = lane >> 2;
     const int b = group * kStreamsPerGroup + s;
     const int C = p.C;
     float lg[kMaxClasses];
     {
-        f32x4 lo = splat4(0.f), hi = splat4(0.f);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const f32x4* row = reinterpret_cast<const f32x4*>(stage + ((w * kFlushSteps + tt) * 16 + s) * 8);
-            lo += row[0];
-            hi += row[1];
-        }
+        const f32x4* row = reinterpret_cast<const f32x4*>(e.lring + (f * 16 + s) * 8);
+        const f32x4 lo = row[0], hi = row[1];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { lg[c] = lo[c]; lg[4 + c] = hi[c]; }
     }
@@ -191,12 +218,10 @@ __device__ __forceinline__ void flush_logits(const GruLayerParams& p, const floa
         if (c < C - 1 && pr[c] > best) { best = pr[c]; word = c - 1; }
     }
     if (!(best > p.decode_thres)) word = -1;
-    int prev = __shfl_up(word, 1);
-    if (tt == 0) prev = carry[s];
-    const int token = (word >= 0 && word != prev) ? word + 1 : 0;   // :76-80
-    if (tt == n - 1) carry[s] = word;
-    if (b < p.B && tt < n) {
-        const size_t row = (size_t)b * p.T + (t0 + tt);
+    e.words[f * 16 + s] = word;
+    const bool mine = b < p.B && f < n;
+    const size_t row = (size_t)b * p.T + (t0 + f);
+    if (mine) {
         if (C == 6) {       // rows are 24 B: three 8-byte stores
             if (p.logits) {
                 float2* o = reinterpret_cast<float2*>(p.logits + row * 6);
@@ -218,9 +243,16 @@ __device__ __forceinline__ void flush_logits(const GruLayerParams& p, const floa
                     if (c < C) p.softmax[row * C + c] = pr[c];
             }
         }
-        if (p.tokens) p.tokens[row] = (int8_t)token;
-        if (final_flush && tt == n - 1 && p.prev_word) p.prev_word[b] = word;
     }
+    lds_barrier();            // every wave's words are in LDS
+    const int blk = (t0 / kRingFrames) & 1;
+    const int prev = f == 0 ? e.carry[blk * 16 + s] : e.words[(f - 1) * 16 + s];
+    const int token = (word >= 0 && word != prev) ? word + 1 : 0;   // utils/prediction.py:76-80
+    if (f == n - 1) {
+        e.carry[(blk ^ 1) * 16 + s] = word;
+        if (final_flush && b < p.B && p.prev_word) p.prev_word[b] = word;
+    }
+    if (mine && p.tokens) p.tokens[row] = (int8_t)token;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,8 +276,7 @@ gru_layer_resident(const GruLayerParams p) {
     f32x4* hbuf = reinterpret_cast<f32x4*>(smem);       // [NT][64]  h_{t-1}, xl layout
     f32x4* rhbuf = hbuf + NT * 64;                       // [NT][64]  r (.) h_{t-1}
     f32x4* wlds = rhbuf + NT * 64;                       // [4 waves][KCX][64] gate x-part: {r0,u0,r1,u1}
-    float* stage = reinterpret_cast<float*>(wlds + 4 * KCX * 64);   // LAST: [4][kFlushSteps][16][8]
-    int* carry = reinterpret_cast<int*>(stage + 4 * kFlushSteps * 16 * 8);  // LAST: [16]
+    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(wlds + 4 * KCX * 64));   // LAST only
 
     // ---- stage weights: registers (recurrent + candidate) and LDS (gate x-part) ------------------
     // p.wh is the group-of-4 layout [NT][3][KCH/4][64][4]: one dwordx4 per four fragments.  p.wx is the
@@ -346,7 +377,7 @@ gru_layer_resident(const GruLayerParams p) {
         const int bb = group * kStreamsPerGroup + tid;
         int pw = -1;
         if (bb < p.B && p.prev_word && !(p.reset && p.reset[bb])) pw = p.prev_word[bb];
-        carry[tid] = pw;
+        epi.carry[tid] = pw;          // block 0 reads carry[0][.]
     }
 
     // ---- x stream --------------------------------------------------------------------------------
@@ -568,8 +599,7 @@ gru_layer_resident(const GruLayerParams p) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) accf = mfma4(wfc[j][e], hout[j][e], accf);
-            if (g < 2)
-                *reinterpret_cast<f32x4*>(stage + ((w * kFlushSteps + (t & (kFlushSteps - 1))) * 16 + s) * 8 + 4 * g) = accf;
+            if (g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
         }
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NPRE>(cand_x_mfma);     // most of frame t+1's candidate x-part covers the LDS write
@@ -586,9 +616,13 @@ gru_layer_resident(const GruLayerParams p) {
         static_for<NPRE, NCX>(cand_x_mfma);   // the rest of frame t+1's candidate x-part hides the hbuf read
         __builtin_amdgcn_sched_barrier(0);
 #ifndef KWS_ABL_NOFLUSH
-        if (LAST && w == 0 && (((t + 1) & (kFlushSteps - 1)) == 0 || t == T - 1)) {
-            const int t0 = t & ~(kFlushSteps - 1);
-            flush_logits(p, stage, carry, group, t0, t - t0 + 1, lane, t == T - 1);
+        if (LAST) {
+            if (w == (t & 3)) epilogue_fold(epi, t, lane);
+            if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
+                const int t0 = t & ~(kRingFrames - 1);
+                lds_barrier();                       // the fold of frame t is visible to every wave
+                epilogue_flush(p, epi, group, t0, t - t0 + 1, w, lane, t == T - 1);
+            }
         }
 #endif
     };
@@ -650,8 +684,7 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* hbuf = reinterpret_cast<f32x4*>(smem);
     f32x4* rhbuf = hbuf + NT * 64;
-    float* stage = reinterpret_cast<float*>(rhbuf + NT * 64);
-    int* carry = reinterpret_cast<int*>(stage + 4 * kFlushSteps * 16 * 8);
+    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(rhbuf + NT * 64));   // LAST only
 
     const f32x4* wx = reinterpret_cast<const f32x4*>(p.wx);   // [NT][3][KCX4][64]
     const f32x4* wh = reinterpret_cast<const f32x4*>(p.wh);   // [NT][3][NT][64]
@@ -675,7 +708,7 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
             const int bb = group * kStreamsPerGroup + tid;
             int pw = -1;
             if (bb < p.B && p.prev_word && !(p.reset && p.reset[bb])) pw = p.prev_word[bb];
-            carry[tid] = pw;
+            epi.carry[tid] = pw;
         }
     }
     const float* xrow = FIRST ? p.x_mel + (size_t)b * T * I : nullptr;
@@ -776,12 +809,15 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
                 for (int e = 0; e < 4; ++e) accf = mfma4(p.wfc[(n * 4 + e) * 64 + lane], hout[e], accf);
             }
         }
-        if (LAST && g < 2)
-            *reinterpret_cast<f32x4*>(stage + ((w * kFlushSteps + (t & (kFlushSteps - 1))) * 16 + s) * 8 + 4 * g) = accf;
+        if (LAST && g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
         __syncthreads();
-        if (LAST && w == 0 && (((t + 1) & (kFlushSteps - 1)) == 0 || t == T - 1)) {
-            const int t0 = t & ~(kFlushSteps - 1);
-            flush_logits(p, stage, carry, group, t0, t - t0 + 1, lane, t == T - 1);
+        if (LAST) {
+            if (w == (t & 3)) epilogue_fold(epi, t, lane);
+            if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
+                const int t0 = t & ~(kRingFrames - 1);
+                __syncthreads();
+                epilogue_flush(p, epi, group, t0, t - t0 + 1, w, lane, t == T - 1);
+            }
         }
     }
     if (bvalid) {
@@ -796,12 +832,12 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
 // ------------------------------------------------------------------------------------------------
 static size_t resident_lds_bytes(int kcx, bool last) {
     size_t n = 2 * 8 * 64 * 16 + (size_t)4 * kcx * 64 * 16;
-    if (last) n += 4 * kFlushSteps * 16 * 8 * 4 + 16 * 4;
+    if (last) n += kEpilogueLdsBytes;
     return n;
 }
 static size_t generic_lds_bytes(int hidden, bool last) {
     size_t n = (size_t)2 * (hidden / 16) * 64 * 16;
-    if (last) n += 4 * kFlushSteps * 16 * 8 * 4 + 16 * 4;
+    if (last) n += kEpilogueLdsBytes;
     return n;
 }
 
