@@ -149,6 +149,7 @@ __device__ __forceinline__ void lds_barrier() {
 //   words  [16 frames][16 streams]      carry [2][16]   (previous block's last word, ping-pong)
 // ------------------------------------------------------------------------------------------------
 constexpr int kRingFrames = 16;
+constexpr int xs_stride(int kcx) { return 4 * ((((kcx + 3) / 4) & 1) ? (kcx + 3) / 4 : (kcx + 3) / 4 + 1); }
 struct EpilogueLds {
     float* pstage;
     float* lring;
@@ -277,6 +278,10 @@ gru_layer_resident(const GruLayerParams p) {
     f32x4* rhbuf = hbuf + NT * 64;                       // [NT][64]  r (.) h_{t-1}
     f32x4* wlds = rhbuf + NT * 64;                       // [4 waves][KCX][64] gate x-part: {r0,u0,r1,u1}
     const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(wlds + 4 * KCX * 64));   // LAST only
+    // FIRST only: one frame of mel for the group, [16 streams x 4 lane groups][kXsStride] floats, row
+    // (4s+g) holds x[s][4*kc+g] for kc = 0..KCX-1 -- each lane's B operands are contiguous
+    constexpr int kXsStride = xs_stride(KCX);       // 4 * odd: rows 16 apart in one ds_read_b128 group spread over the banks
+    float* xs = reinterpret_cast<float*>(reinterpret_cast<char*>(wlds + 4 * KCX * 64) + (LAST ? kEpilogueLdsBytes : 0));
 
     // ---- stage weights: registers (recurrent + candidate) and LDS (gate x-part) ------------------
     // p.wh is the group-of-4 layout [NT][3][KCH/4][64][4]: one dwordx4 per four fragments.  p.wx is the
@@ -381,37 +386,56 @@ gru_layer_resident(const GruLayerParams p) {
     }
 
     // ---- x stream --------------------------------------------------------------------------------
-    // First layer: mel rows, prefetched TWO frames ahead into a double buffer.  vmcnt counts stores
-    // too, so with a one-frame distance the wait for x(t+1) would also wait for the acks of frame
-    // t-1's scratch stores (issued just before the loads) and the jitter would surface as barrier skew.
-    // Upper layers: the previous layer's xl-layout block, one frame ahead (32 registers, no room for two).
-    constexpr int XD = FIRST ? 2 : 1;
-    const float* xrow = FIRST ? p.x_mel + (size_t)b * T * p.I : nullptr;
+    // First layer: the four waves fetch the group's mel frame COOPERATIVELY -- wave w loads streams
+    // 4w..4w+3 (one global_load_dwordx4, 4*I/4 active lanes) two frames ahead, scatters it into `xs`
+    // late in the frame, and every wave reads its B operands back with three LDS reads.  A global load
+    // costs ~30 cycles of MFMA time and an LDS read ~2.4 (tools/ubench/mfma_operands.hip); ten divergent
+    // dword loads per wave per frame were 4.5 % of this kernel.
+    // Upper layers: the previous layer's xl-layout block, one slice per MFMA group (a burst of loads from
+    // four phase-locked waves backs up the address path and stalls the MFMAs queued behind it).
+    constexpr int XQ = KCX;                          // float4 pieces per mel row (I == 4*KCX)
+    const int xl_row = lane / XQ, xl_q = lane % XQ;  // this lane's (stream-in-quarter, piece)
+    const bool xl_active = FIRST && lane < 4 * XQ;
+    const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
+    const float4* xl_src = FIRST ? reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * T * p.I) + xl_q : nullptr;
+    float4 xl_inflight = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto coop_issue = [&](int t_req) {               // global -> register (in flight)
+        const int t = t_req < T ? t_req : T - 1;
+        if (xl_active) xl_inflight = xl_src[(size_t)t * XQ];
+    };
+    auto coop_commit = [&]() {                       // register -> xs
+        if (xl_active) {
+            float* dst = xs + (4 * (4 * w + xl_row)) * kXsStride + xl_q;
+            dst[0 * kXsStride] = xl_inflight.x;
+            dst[1 * kXsStride] = xl_inflight.y;
+            dst[2 * kXsStride] = xl_inflight.z;
+            dst[3 * kXsStride] = xl_inflight.w;
+        }
+    };
     const float4* xprev = FIRST ? nullptr : p.x_prev + (size_t)group * T * NT * 64 + lane;
-    float xbuf0[KCX], xbuf1[KCX];   // xbuf1 is dead (and removed) when XD == 1
-    // x is fetched in NT slices so the loads can be dripped into the instruction stream one per MFMA
-    // group: a burst of 10 divergent loads issued by four phase-locked waves at once backs up the
-    // address path and, issue being in order, stalls the MFMAs queued behind it (~900 cycles/frame).
-    auto load_x_slice = [&](float (&dst)[KCX], int t_req, const int sl) {   // sl: unrolled constant
+    float xbuf0[KCX];
+    auto read_xs = [&](float (&dst)[KCX]) {          // xs -> this lane's B operands
+        const float* row = xs + (4 * s + g) * kXsStride;
+#pragma unroll
+        for (int k4 = 0; k4 < KCX / 4; ++k4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * k4);
+            dst[4 * k4 + 0] = v[0]; dst[4 * k4 + 1] = v[1]; dst[4 * k4 + 2] = v[2]; dst[4 * k4 + 3] = v[3];
+        }
+        if constexpr (KCX % 4 >= 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(row + (KCX / 4) * 4);
+            dst[(KCX / 4) * 4 + 0] = v[0]; dst[(KCX / 4) * 4 + 1] = v[1];
+        }
+        if constexpr (KCX % 2 == 1) dst[KCX - 1] = row[KCX - 1];
+    };
+    auto load_x_slice = [&](float (&dst)[KCX], int t_req, const int sl) {   // upper layers; sl: unrolled constant
 #ifdef KWS_ABL_NOXLOAD
         return;
 #endif
-        const int t = t_req < T ? t_req : T - 1;
-        if constexpr (FIRST) {
-#pragma unroll
-            for (int kc = sl; kc < KCX; kc += NT) {
-                // rows k >= I carry zero weights: clamp the address instead of predicating the load
-                const int k = 4 * kc + g;
-                dst[kc] = xrow[(size_t)t * p.I + (k < p.I ? k : p.I - 1)];
-            }
-        } else {
+        if constexpr (!FIRST) {
+            const int t = t_req < T ? t_req : T - 1;
             const float4 v = xprev[((size_t)t * NT + sl) * 64];
             dst[4 * sl + 0] = v.x; dst[4 * sl + 1] = v.y; dst[4 * sl + 2] = v.z; dst[4 * sl + 3] = v.w;
         }
-    };
-    auto load_x = [&](float (&dst)[KCX], int t_req) {
-#pragma unroll
-        for (int sl = 0; sl < NT; ++sl) load_x_slice(dst, t_req, sl);
     };
 
     f32x4 acc_r[2], acc_u[2], acc_c[2];
@@ -459,8 +483,7 @@ gru_layer_resident(const GruLayerParams p) {
 #endif
     f32x4 hb_a, hb_b;            // exchange-read pipeline registers (two float4 in flight)
 
-    // One frame.  xcur holds x(t+1) on entry (XD == 2) or receives it first (XD == 1, xcur == xnxt);
-    // xnxt receives x(t+XD).
+    // One frame (xcur == xnxt == the single B-operand buffer: x(t+1) lands in it during this frame).
     auto frame = [&](int t, float (&xcur)[KCX], float (&xnxt)[KCX]) {
         KWS_TS(0);            // [B2 .. here]: hb reads + post-barrier cand_x
         // gates, h-part:  acc_{r,u} += Wg[I:,:]^T h_{t-1}   (hb_a/hb_b were fetched behind cand_x);
@@ -473,7 +496,7 @@ gru_layer_resident(const GruLayerParams p) {
                 if (nn & 1) hb_b = hbuf[(nn + 2) * 64 + lane]; else hb_a = hbuf[(nn + 2) * 64 + lane];
             }
 #endif
-            load_x_slice(xnxt, t + XD, nn);
+            if constexpr (FIRST) { if (nn == 0) coop_issue(t + 2); } else load_x_slice(xnxt, t + 1, nn);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -487,6 +510,7 @@ gru_layer_resident(const GruLayerParams p) {
         }
         mfma_fence(acc_r[0], acc_u[0], acc_r[1], acc_u[1]);
         KWS_TS(1);            // gates_h
+        if constexpr (FIRST) read_xs(xcur);          // x(t+1), committed to LDS during frame t-1
         // ---- region A: the 16 sigmoids as one VALU cluster (r first so r(.)h reaches LDS early), then the
         // first half of frame t+1's gate x-part as cover for the exchange
         f32x4 u[2];
@@ -583,6 +607,7 @@ gru_layer_resident(const GruLayerParams p) {
             if constexpr (m % 2 == 0) acc_c[0] = mfma4(wcx[0][kc], xcur[kc], acc_c[0]);
             else acc_c[1] = mfma4(wcx[1][kc], xcur[kc], acc_c[1]);
         };
+        if constexpr (FIRST) coop_commit();          // x(t+2): visible after barrier #2, read in frame t+1
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             hbuf[(2 * w + j) * 64 + lane] = hreg[j];
@@ -628,24 +653,29 @@ gru_layer_resident(const GruLayerParams p) {
     };
 
     if (T > 0) {
-        load_x(xbuf0, 0);
-        if constexpr (FIRST) load_x(xbuf1, 1);
+        if constexpr (FIRST) {
+            coop_issue(0);
+            coop_commit();
+            __syncthreads();
+            read_xs(xbuf0);                          // x(0)
+            coop_issue(1);
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < NT; ++sl) load_x_slice(xbuf0, 0, sl);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
         gates_x_part(xbuf0, k_lo{}, k_hi{}, pinned{});
         hb_a = hbuf[0 * 64 + lane];
         hb_b = hbuf[1 * 64 + lane];
         cand_x(xbuf0);
-    }
-    if constexpr (FIRST) {
-        // xbuf1 holds x(t+1) on even frames, xbuf0 on odd ones
-        for (int t = 0; t < T; t += 2) {
-            frame(t, xbuf1, xbuf0);
-            if (t + 1 < T) frame(t + 1, xbuf0, xbuf1);
+        if constexpr (FIRST) {
+            __syncthreads();                         // every wave has read x(0) out of xs
+            coop_commit();                           // x(1)
+            __syncthreads();
         }
-    } else {
-        for (int t = 0; t < T; ++t) frame(t, xbuf0, xbuf0);
     }
+    for (int t = 0; t < T; ++t) frame(t, xbuf0, xbuf0);
 
 #ifdef KWS_TIMING
     if (p.dbg && lane == 0) {
@@ -830,9 +860,10 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static size_t resident_lds_bytes(int kcx, bool last) {
+static size_t resident_lds_bytes(int kcx, bool first, bool last) {
     size_t n = 2 * 8 * 64 * 16 + (size_t)4 * kcx * 64 * 16;
     if (last) n += kEpilogueLdsBytes;
+    if (first) n += (size_t)64 * xs_stride(kcx) * 4;
     return n;
 }
 static size_t generic_lds_bytes(int hidden, bool last) {
@@ -846,8 +877,7 @@ int gru_resident_kcx(int in_dim, bool first) { return first ? (in_dim + 3) / 4 :
 bool gru_resident_supported(int hidden, int in_dim, bool first) {
     if (hidden != 128) return false;
     if (!first) return in_dim == 128;
-    const int kcx = (in_dim + 3) / 4;
-    return kcx == 10 || kcx == 15;
+    return in_dim == 40 || in_dim == 60;     // instantiated KCX = 10, 15; rows must be whole float4s
 }
 
 template <typename K>
@@ -865,7 +895,7 @@ static hipError_t launch_with_lds(K kernel, const GruLayerParams& p, size_t lds,
 }
 
 hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool last, hipStream_t st) {
-    const size_t lds = resident_lds_bytes(p.KCX, last);
+    const size_t lds = resident_lds_bytes(p.KCX, first, last);
 #define KWS_RES(KCX_, F_, L_) return launch_with_lds(gru_layer_resident<KCX_, F_, L_>, p, lds, st)
     if (first) {
         if (p.KCX == 10) { if (last) KWS_RES(10, true, true); else KWS_RES(10, true, false); }
