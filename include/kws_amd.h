@@ -57,7 +57,10 @@ typedef struct kws_config {
     int32_t num_classes; /* C : 3..8 (space, words..., blank)                               */
     int32_t use_relu;    /* models/rnn_ctc.py:280                                           */
     float value_clip;    /* models/rnn_ctc.py:282 : >0 and use_relu -> clip logits to [0,20] */
+    int32_t precision;   /* KWS_FP32 (reference arithmetic) or KWS_BF16 (BASELINE configs[2]: bf16 weights and
+                            matmul inputs, fp32 accumulate / state / activations; H=128, L<=2, n_mel%4==0, <=64) */
 } kws_config;
+enum { KWS_FP32 = 0, KWS_BF16 = 1 };
 
 typedef struct kws_model* kws_handle;
 

@@ -13,12 +13,13 @@ KWS_ERR_NO_DEVICE = -4
 KWS_ERR_OUT_OF_MEMORY = -5
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_RESIDENT = 0, 1, 2
 DECODE, DECODE2, DECODE_STRICT = 0, 1, 2
+FP32, BF16 = 0, 1
 
 
 class KwsConfig(ctypes.Structure):
     _fields_ = [("n_mel", ctypes.c_int32), ("hidden", ctypes.c_int32), ("num_layers", ctypes.c_int32),
                 ("num_classes", ctypes.c_int32), ("use_relu", ctypes.c_int32),
-                ("value_clip", ctypes.c_float)]
+                ("value_clip", ctypes.c_float), ("precision", ctypes.c_int32)]
 
 
 class KwsError(RuntimeError):

@@ -1,0 +1,306 @@
+// bf16 variant of the streaming GRU stack (BASELINE.json configs[2]): bf16 weights and bf16 matmul inputs,
+// fp32 accumulation, fp32 recurrent state, fp32 activations / logits.  Same semantics as gru_kernels.hip
+// (models/rnn_ctc.py:155-165,202-284), same boundary; only the operand precision differs.
+//
+// Mapping: v_mfma_f32_16x16x32_bf16, D[unit][stream] as in the fp32 kernels (A = weights, B = activations,
+// 16 streams per workgroup, wave w owns units [32w, 32w+32)).  One k-chunk is 32 inputs; lane (g, s/i) holds
+// 8 consecutive k of it.  K is permuted so that chunk m of a hidden vector is exactly what wave m produces:
+//   lane (g,s), j = 0..3 -> unit 32m + 4g + j ; j = 4..7 -> unit 32m + 16 + 4g + (j-4)
+// i.e. the wave's two fp32 C tiles, rounded to bf16 and packed, ARE the B operand of chunk m: the
+// exchange is one ds_write_b128 per wave and four ds_read_b128 per consumer, no transpose.
+//
+// At bf16 MFMA rates (16 cycles per 16x16x32) both layers' weights fit the register file (84 operands x 4
+// VGPRs = 336 of 512) and the matrix work of a frame is ~1.4k cycles, so the whole stack runs FUSED in one
+// launch with no inter-layer HBM scratch; activations, LDS exchange and barriers dominate.
+#include "gru_device.h"
+
+namespace kws {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// A operand straight from AGPRs (see KWS_MFMA_A in gru_device.h)
+#define KWS_MFMA_BF16_A(acc, wa, bv) \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wa), "v"(bv))
+
+// two fp32 -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32 has no builtin)
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int KX0, int NL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gru_stack_bf16(const GruBf16Params p) {
+    constexpr int H = 128;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, g = lane >> 4, s = lane & 15;
+    const int group = blockIdx.x;
+    const int b_raw = group * kStreamsPerGroup + s;
+    const bool bvalid = b_raw < p.B;
+    const int b = bvalid ? b_raw : p.B - 1;
+    const int T = p.T;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* hb = reinterpret_cast<u32x4*>(smem);             // [NL][4 chunks][64]  h_{t-1} (bf16)
+    u32x4* rhb = hb + NL * 4 * 64;                           // [NL][4][64]         r (.) h_{t-1}
+    u32x4* xsb = rhb + NL * 4 * 64;                          // [KX0][64]           mel frame (bf16), zero padded
+    float* biasl = reinterpret_cast<float*>(xsb + KX0 * 64); // [NL][3][128]
+    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + NL * 3 * H));
+
+    // ---- weights: layer 1 (48 operands) + the first 8 of layer 0 in AGPRs, the rest in VGPRs -------------
+    constexpr int KC0 = KX0 + 4, KC1 = 8;
+    bf16x8 w0[2][3][KC0];        // [tile][gate][chunk]
+    bf16x8 w1[NL > 1 ? 2 : 1][3][KC1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int c = 0; c < KC0; ++c) w0[j][q][c] = as_bf16x8(reinterpret_cast<const u32x4*>(p.w[0])[(((2 * w + j) * 3 + q) * KC0 + c) * 64 + lane]);
+            if constexpr (NL > 1) {
+#pragma unroll
+                for (int c = 0; c < KC1; ++c) w1[j][q][c] = as_bf16x8(reinterpret_cast<const u32x4*>(p.w[1])[(((2 * w + j) * 3 + q) * KC1 + c) * 64 + lane]);
+            }
+        }
+    if constexpr (NL > 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < KC1; ++c) asm volatile("" : "+a"(w1[j][q][c]));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = KX0; c < KC0; ++c) asm volatile("" : "+a"(w0[j][0][c]));    // r-gate h-part of layer 0
+    asm volatile("s_nop 7" ::: "memory");
+    const bf16x8 wfc = as_bf16x8(reinterpret_cast<const u32x4*>(p.wfc)[w * 64 + lane]);
+    f32x4 bfc4 = splat4(0.f);
+    if (w == 0) bfc4 = ld4(p.bfc + 4 * g);
+
+    // ---- LDS init: biases, zeroed mel staging, initial state -------------------------------------------
+    for (int i = tid; i < NL * 3 * H; i += 256) biasl[i] = p.bias[i / (3 * H)][i % (3 * H)];
+    for (int i = tid; i < KX0 * 64; i += 256) xsb[i] = (u32x4){0u, 0u, 0u, 0u};
+    const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
+    const int len_s = p.seq_len ? p.seq_len[b] : T;
+    f32x4 hreg[NL][2];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            hreg[l][j] = do_reset ? splat4(0.f)
+                                  : ld4(p.state_in + ((size_t)l * p.B + b) * H + (2 * w + j) * 16 + 4 * g);
+        hb[(l * 4 + w) * 64 + lane] = (u32x4){pack_bf16(hreg[l][0][0], hreg[l][0][1]), pack_bf16(hreg[l][0][2], hreg[l][0][3]),
+                                               pack_bf16(hreg[l][1][0], hreg[l][1][1]), pack_bf16(hreg[l][1][2], hreg[l][1][3])};
+    }
+    if (tid < 16) {
+        const int bb = group * kStreamsPerGroup + tid;
+        int pw = -1;
+        if (bb < p.B && p.epi.prev_word && !(p.reset && p.reset[bb])) pw = p.epi.prev_word[bb];
+        epi.carry[tid] = pw;
+    }
+
+    // ---- mel: wave w fetches streams 4w..4w+3 (one dwordx4 per lane), rounds to bf16, scatters into the
+    // B-operand image: k = 4q+e -> chunk k/32, lane group (k%32)/8, element k%8 ------------------------------
+    const int XQ = p.I / 4;                               // float4 pieces per mel row (I % 4 == 0)
+    const int xl_row = lane / XQ, xl_q = lane % XQ;
+    const bool xl_active = lane < 4 * XQ;
+    const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
+    const float4* xl_src = reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * T * p.I) + xl_q;
+    unsigned* xs_dst = reinterpret_cast<unsigned*>(xsb) +
+                       (((xl_q * 4) / 32) * 64 + (((xl_q * 4) % 32) / 8) * 16 + (4 * w + xl_row)) * 4 + ((xl_q * 4) % 8) / 2;
+    float4 fl_a = make_float4(0.f, 0.f, 0.f, 0.f), fl_b = fl_a;     // two frames in flight
+    auto fetch = [&](float4& r, int t_req) { if (xl_active) r = xl_src[(size_t)(t_req < T ? t_req : T - 1) * XQ]; };
+    auto commit = [&](const float4& r) {
+        if (xl_active) *reinterpret_cast<uint2*>(xs_dst) = make_uint2(pack_bf16(r.x, r.y), pack_bf16(r.z, r.w));
+    };
+
+    __syncthreads();
+    if (T > 0) {
+        fetch(fl_a, 0);
+        commit(fl_a);                 // x(0)
+        fetch(fl_b, 1);               // x(1): committed during frame 0
+        fetch(fl_a, 2);               // x(2): committed during frame 1
+        __syncthreads();
+    }
+
+    // one GRU layer for one frame; xB/nx = this layer's input chunks, returns with hreg[l] updated, hb[l] rewritten
+    auto layer = [&](auto l_, const bf16x8* xB, auto nx_, int t, f32x4 (&hout)[2]) {
+        constexpr int l = decltype(l_)::value, NX = decltype(nx_)::value;
+        const f32x4* bl = reinterpret_cast<const f32x4*>(biasl + l * 3 * H);
+        f32x4 acc_r[2], acc_u[2], acc_c[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc_r[j] = bl[(0 * H + (2 * w + j) * 16) / 4 + g];
+            acc_u[j] = bl[(1 * H + (2 * w + j) * 16) / 4 + g];
+            acc_c[j] = bl[(2 * H + (2 * w + j) * 16) / 4 + g];
+        }
+        bf16x8 hB[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hB[m] = as_bf16x8(hb[(l * 4 + m) * 64 + lane]);
+        // x-part of all three gates, then the gate h-part
+        if constexpr (l != 0) { mfma_prefence(acc_r[0], acc_u[0], acc_r[1], acc_u[1]); mfma_prefence(acc_c[0], acc_c[1]); }
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (l == 0) {
+                    acc_r[j] = mfma_bf16(w0[j][0][c], xB[c], acc_r[j]);
+                    acc_u[j] = mfma_bf16(w0[j][1][c], xB[c], acc_u[j]);
+                    acc_c[j] = mfma_bf16(w0[j][2][c], xB[c], acc_c[j]);
+                } else {
+                    KWS_MFMA_BF16_A(acc_r[j], w1[j][0][c], xB[c]);
+                    KWS_MFMA_BF16_A(acc_u[j], w1[j][1][c], xB[c]);
+                    KWS_MFMA_BF16_A(acc_c[j], w1[j][2][c], xB[c]);
+                }
+            }
+        }
+        mfma_prefence(acc_r[0], acc_u[0], acc_r[1], acc_u[1]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (l == 0) {
+                    KWS_MFMA_BF16_A(acc_r[j], w0[j][0][NX + m], hB[m]);
+                    acc_u[j] = mfma_bf16(w0[j][1][NX + m], hB[m], acc_u[j]);
+                } else {
+                    KWS_MFMA_BF16_A(acc_r[j], w1[j][0][NX + m], hB[m]);
+                    KWS_MFMA_BF16_A(acc_u[j], w1[j][1][NX + m], hB[m]);
+                }
+            }
+        }
+        mfma_fence(acc_r[0], acc_u[0], acc_r[1], acc_u[1]);
+        f32x4 u[2], rh[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x2 r_lo = sigmoid2((f32x2){acc_r[j][0], acc_r[j][1]});
+            const f32x2 r_hi = sigmoid2((f32x2){acc_r[j][2], acc_r[j][3]});
+            const f32x2 a = r_lo * (f32x2){hreg[l][j][0], hreg[l][j][1]};
+            const f32x2 c2 = r_hi * (f32x2){hreg[l][j][2], hreg[l][j][3]};
+            rh[j] = (f32x4){a.x, a.y, c2.x, c2.y};
+        }
+        rhb[(l * 4 + w) * 64 + lane] = (u32x4){pack_bf16(rh[0][0], rh[0][1]), pack_bf16(rh[0][2], rh[0][3]),
+                                                pack_bf16(rh[1][0], rh[1][1]), pack_bf16(rh[1][2], rh[1][3])};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x2 u_lo = sigmoid2((f32x2){acc_u[j][0], acc_u[j][1]});
+            const f32x2 u_hi = sigmoid2((f32x2){acc_u[j][2], acc_u[j][3]});
+            u[j] = (f32x4){u_lo.x, u_lo.y, u_hi.x, u_hi.y};
+        }
+        lds_barrier();            // r(.)h visible; hb[l] fully consumed
+        mfma_prefence(acc_c[0], acc_c[1]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const bf16x8 rB = as_bf16x8(rhb[(l * 4 + m) * 64 + lane]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (l == 0) acc_c[j] = mfma_bf16(w0[j][2][NX + m], rB, acc_c[j]);
+                else KWS_MFMA_BF16_A(acc_c[j], w1[j][2][NX + m], rB);
+            }
+        }
+        mfma_fence(acc_c[0], acc_c[1]);
+        const unsigned live = t < len_s ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f32x2 c = tanh2((f32x2){acc_c[j][2 * h2], acc_c[j][2 * h2 + 1]});
+                const f32x2 uu = {u[j][2 * h2], u[j][2 * h2 + 1]};
+                const f32x2 hh = {hreg[l][j][2 * h2], hreg[l][j][2 * h2 + 1]};
+                const f32x2 hn = (1.0f - uu) * c + uu * hh;
+                hreg[l][j][2 * h2] = bitsel(live, hn.x, hh.x);
+                hreg[l][j][2 * h2 + 1] = bitsel(live, hn.y, hh.y);
+                hout[j][2 * h2] = bitsel(live, hn.x, 0.f);
+                hout[j][2 * h2 + 1] = bitsel(live, hn.y, 0.f);
+            }
+        }
+        hb[(l * 4 + w) * 64 + lane] = (u32x4){pack_bf16(hreg[l][0][0], hreg[l][0][1]), pack_bf16(hreg[l][0][2], hreg[l][0][3]),
+                                               pack_bf16(hreg[l][1][0], hreg[l][1][1]), pack_bf16(hreg[l][1][2], hreg[l][1][3])};
+    };
+
+    auto frame = [&](int t, float4& fl_commit, float4& /*unused*/) {
+        bf16x8 xB[KX0];
+#pragma unroll
+        for (int c = 0; c < KX0; ++c) xB[c] = as_bf16x8(xsb[c * 64 + lane]);
+        f32x4 hout[2];
+        layer(std::integral_constant<int, 0>{}, xB, std::integral_constant<int, KX0>{}, t, hout);
+        // xsb was read by every wave before the barrier inside layer 0: stage x(t+1), request x(t+3)
+        commit(fl_commit);
+        fetch(fl_commit, t + 3);
+        lds_barrier();            // h0(t) (and x(t+1)) visible
+        if constexpr (NL > 1) {
+            bf16x8 x1B[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) x1B[m] = as_bf16x8(hb[(0 * 4 + m) * 64 + lane]);
+            layer(std::integral_constant<int, 1>{}, x1B, std::integral_constant<int, 4>{}, t, hout);
+        }
+        // dense: this wave's 32 units are exactly k-chunk w of Wfc^T
+        const bf16x8 hB = as_bf16x8((u32x4){pack_bf16(hout[0][0], hout[0][1]), pack_bf16(hout[0][2], hout[0][3]),
+                                             pack_bf16(hout[1][0], hout[1][1]), pack_bf16(hout[1][2], hout[1][3])});
+        u32x4 hBv = __builtin_bit_cast(u32x4, hB);
+        asm volatile("s_nop 3" : "+v"(hBv));      // v_cvt_pk (inline asm) -> MFMA SrcB distance
+        const f32x4 accf = mfma_bf16(wfc, __builtin_bit_cast(bf16x8, hBv), bfc4);
+        if (g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
+        lds_barrier();            // top-layer h(t) and the partial logits visible
+        if (w == (t & 3)) epilogue_fold(epi, t, lane);
+        if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
+            const int t0 = t & ~(kRingFrames - 1);
+            lds_barrier();
+            epilogue_flush(p.epi, epi, group, t0, t - t0 + 1, w, lane, t == T - 1);
+        }
+    };
+    // fl_b holds x(t+1) on even frames, fl_a on odd ones
+    for (int t = 0; t < T; t += 2) {
+        frame(t, fl_b, fl_a);
+        if (t + 1 < T) frame(t + 1, fl_a, fl_b);
+    }
+
+    if (bvalid) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<f32x4*>(p.state_out + ((size_t)l * p.B + b) * H + (2 * w + j) * 16 + 4 * g) = hreg[l][j];
+    }
+}
+
+size_t gru_bf16_lds_bytes(int kx0, int nl) {
+    return (size_t)(2 * nl * 4 * 64 + kx0 * 64) * 16 + (size_t)nl * 3 * 128 * 4 + kEpilogueLdsBytes;
+}
+
+bool gru_bf16_supported(int hidden, int n_mel, int layers) {
+    return hidden == 128 && n_mel % 4 == 0 && n_mel >= 4 && n_mel <= 64 && layers >= 1 && layers <= 2;
+}
+
+template <int KX0, int NL>
+static hipError_t launch_bf16(const GruBf16Params& p, hipStream_t st) {
+    const size_t lds = gru_bf16_lds_bytes(KX0, NL);
+    static size_t granted = 0;
+    if (lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_stack_bf16<KX0, NL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted = lds;
+    }
+    const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
+    hipLaunchKernelGGL((gru_stack_bf16<KX0, NL>), dim3(groups), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st) {
+    if (kx0 == 1 && nl == 1) return launch_bf16<1, 1>(p, st);
+    if (kx0 == 1 && nl == 2) return launch_bf16<1, 2>(p, st);
+    if (kx0 == 2 && nl == 1) return launch_bf16<2, 1>(p, st);
+    if (kx0 == 2 && nl == 2) return launch_bf16<2, 2>(p, st);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace kws

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <string>
@@ -49,6 +50,9 @@ struct kws_model {
     int kernel_kind = KWS_KERNEL_AUTO;
     std::vector<LayerDev> layers;
     size_t wfc_off = 0, bfc_off = 0;
+    // bf16 stack: offsets (floats) of the packed bf16 A operands
+    size_t bf_w[2] = {0, 0}, bf_wfc = 0;
+    int bf_kx0 = 0;
     float* d_weights = nullptr;
     float4* scratch[2] = {nullptr, nullptr};
     size_t scratch_bytes = 0;
@@ -69,6 +73,12 @@ bool config_ok(const kws_config* c, int* code) {
     if (c->num_layers < 1 || c->num_layers > 8) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "num_layers=%d out of range [1,8]", c->num_layers); return false; }
     if (c->num_classes < 3 || c->num_classes > kws::kMaxClasses) { *code = fail(KWS_ERR_UNSUPPORTED, "num_classes=%d unsupported (3..8)", c->num_classes); return false; }
     if (c->hidden != 64 && c->hidden != 128 && c->hidden != 256) { *code = fail(KWS_ERR_UNSUPPORTED, "hidden=%d unsupported (64, 128, 256)", c->hidden); return false; }
+    if (c->precision != KWS_FP32 && c->precision != KWS_BF16) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "unknown precision %d", c->precision); return false; }
+    if (c->precision == KWS_BF16 && !kws::gru_bf16_supported(c->hidden, c->n_mel, c->num_layers)) {
+        *code = fail(KWS_ERR_UNSUPPORTED, "bf16 path needs hidden=128, num_layers<=2, n_mel%%4==0 and <=64; got hidden=%d layers=%d n_mel=%d",
+                     c->hidden, c->num_layers, c->n_mel);
+        return false;
+    }
     return true;
 }
 
@@ -91,6 +101,17 @@ inline int kmap_interleaved(int kc, int g) { return 4 * kc + g; }
 inline float wq(const float* Wg, const float* Wc, int H, int q, int row, int unit) {
     return q == 2 ? Wc[(size_t)row * H + unit] : Wg[(size_t)row * 2 * H + q * H + unit];
 }
+
+// fp32 -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does)
+inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+// unit of a hidden vector addressed by (chunk m, lane group g, element j) in the bf16 exchange layout
+inline int bf16_unit(int m, int g, int j) { return 32 * m + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)); }
 
 }  // namespace
 
@@ -189,10 +210,56 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
     m->bfc_off = reserve(16);
     for (int i = 0; i < C; ++i) host[m->bfc_off + i] = bfc[i];
 
+    if (cfg->precision == KWS_BF16) {
+        // A operands of v_mfma_f32_16x16x32_bf16: lane (g,i) holds 8 bf16 = W[row(c,g,j)][16n+i], j = 0..7
+        const float* q = static_cast<const float*>(weights_blob);
+        int in_l = cfg->n_mel;
+        m->bf_kx0 = (cfg->n_mel + 31) / 32;
+        for (int l = 0; l < cfg->num_layers; ++l) {
+            const float* Wg = q;
+            const float* Wc = Wg + (size_t)(in_l + H) * 2 * H + 2 * H;
+            const int kx = l == 0 ? m->bf_kx0 : 4, kc = kx + 4;
+            m->bf_w[l] = reserve((size_t)8 * 3 * kc * 64 * 4);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&host[m->bf_w[l]]);
+            for (int n = 0; n < 8; ++n)
+                for (int gq = 0; gq < 3; ++gq)
+                    for (int c = 0; c < kc; ++c)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int g = lane >> 4, i = lane & 15;
+                                int row;
+                                bool ok = true;
+                                if (c < kx) {
+                                    if (l == 0) { row = 32 * c + 8 * g + j; ok = row < in_l; }
+                                    else row = bf16_unit(c, g, j);
+                                } else {
+                                    row = in_l + bf16_unit(c - kx, g, j);
+                                }
+                                const float v = ok ? wq(Wg, Wc, H, gq, row, n * 16 + i) : 0.f;
+                                dst[((((size_t)(n * 3 + gq) * kc + c) * 64 + lane) * 8) + j] = bf16_rne(v);
+                            }
+            q = Wc + (size_t)(in_l + H) * H + H;
+            in_l = H;
+        }
+        m->bf_wfc = reserve((size_t)4 * 64 * 4);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(&host[m->bf_wfc]);
+        for (int c = 0; c < 4; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = lane >> 4, i = lane & 15;
+                    dst[((size_t)c * 64 + lane) * 8 + j] = bf16_rne(i < C ? Wfc[(size_t)bf16_unit(c, g, j) * C + i] : 0.f);
+                }
+    }
+
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_weights), host.size() * sizeof(float));
     if (e != hipSuccess) { delete m; return hip_fail(e, "hipMalloc(weights)"); }
     e = hipMemcpy(m->d_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(m->d_weights); delete m; return hip_fail(e, "hipMemcpy(weights)"); }
+    // A pageable-host hipMemcpy may return once the data is staged; make sure the DMA has landed before
+    // any stream can launch a kernel that reads the fragments (observed: the tail of the upload missing
+    // in the first launch after create).
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { hipFree(m->d_weights); delete m; return hip_fail(e, "hipDeviceSynchronize(weights)"); }
     m->ms_sum.assign(cfg->num_layers, 0.f);
     m->launches.assign(cfg->num_layers, 0);
     *out = m;
@@ -289,6 +356,39 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         return KWS_OK;
     }
     if (!mel) return fail(KWS_ERR_INVALID_ARGUMENT, "mel is null");
+    if (c.precision == KWS_BF16) {
+        if ((reinterpret_cast<uintptr_t>(mel) & 15) != 0) return fail(KWS_ERR_INVALID_ARGUMENT, "mel must be 16-byte aligned");
+        kws::GruBf16Params bp;
+        memset(&bp, 0, sizeof(bp));
+        for (int l = 0; l < L; ++l) {
+            bp.w[l] = reinterpret_cast<const uint4*>(h->d_weights + h->bf_w[l]);
+            bp.bias[l] = h->d_weights + h->layers[l].bias;
+        }
+        bp.wfc = reinterpret_cast<const uint4*>(h->d_weights + h->bf_wfc);
+        bp.bfc = h->d_weights + h->bfc_off;
+        bp.x_mel = mel; bp.state_in = state_in; bp.state_out = state_out;
+        bp.seq_len = seq_len; bp.reset = reset_mask;
+        bp.epi.logits = logits; bp.epi.softmax = softmax; bp.epi.tokens = tokens; bp.epi.prev_word = prev_word;
+        bp.epi.decode_thres = decode2_thres; bp.epi.value_clip = c.value_clip; bp.epi.use_relu = c.use_relu;
+        bp.epi.B = B; bp.epi.T = T; bp.epi.C = c.num_classes;
+        bp.B = B; bp.T = T; bp.I = c.n_mel; bp.L = L;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (h->profiling) {
+            for (hipEvent_t* ev : {&ea, &eb}) {
+                if (!h->event_pool.empty()) { *ev = h->event_pool.back(); h->event_pool.pop_back(); }
+                else KWS_HIP(hipEventCreate(ev));
+            }
+            KWS_HIP(hipEventRecord(ea, st));
+        }
+        hipError_t e = kws::launch_gru_stack_bf16(bp, h->bf_kx0, L, st);
+        if (e != hipSuccess) return hip_fail(e, "launch gru_stack_bf16");
+        if (h->profiling) {
+            KWS_HIP(hipEventRecord(eb, st));
+            h->pending.push_back({0, ea, eb});
+        }
+        return KWS_OK;
+    }
+    if ((reinterpret_cast<uintptr_t>(mel) & 15) != 0) return fail(KWS_ERR_INVALID_ARGUMENT, "mel must be 16-byte aligned");
     int rc = ensure_scratch(h, B, T);
     if (rc != KWS_OK) return rc;
 

@@ -45,6 +45,23 @@ struct GruLayerParams {
     unsigned long long* dbg;  // timing-variant builds only (tools/build_variant.sh -DKWS_TIMING)
 };
 
+// bf16 fused stack (gru_bf16.hip): every layer in one launch, no inter-layer scratch
+struct GruBf16Params {
+    const uint4* w[2];      // per layer: [8 tiles][3 gates][KC_l chunks][64 lanes] bf16x8 A operands (x chunks first)
+    const float* bias[2];   // per layer [3][128] fp32
+    const uint4* wfc;       // [4 chunks][64]  Wfc^T padded to 16 rows
+    const float* bfc;       // [16]
+    const float* x_mel;     // [B,T,I]
+    const float* state_in;  // [L,B,128]
+    float* state_out;
+    const int32_t* seq_len;
+    const uint8_t* reset;
+    GruLayerParams epi;     // logits / softmax / tokens / prev_word / thresholds for the epilogue
+    int B, T, I, L;
+};
+bool gru_bf16_supported(int hidden, int n_mel, int layers);
+hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st);
+
 // launchers (gru_kernels.hip)
 bool gru_resident_supported(int hidden, int in_dim, bool first);
 int gru_resident_kcx(int in_dim, bool first);

@@ -173,3 +173,51 @@ def stream_chunks(w, mel, chunk_lens, dtype=np.float32):
         outs.append(lg)
         pos += n
     return np.concatenate(outs, axis=1), state
+
+
+# --------------------------------------------------------------------------------------
+# bf16 variant (BASELINE configs[2]) -- restatement of WHERE the HIP bf16 path rounds, not a new
+# reference: the reference has no bf16 model.  Matmul inputs (weights, x, h, r*h, top-layer h) are
+# rounded to bf16 (nearest even); products are exact in fp32, accumulation / activations / state stay
+# in higher precision.  PARITY UNPINNED like the fp32 GRU oracle.
+# --------------------------------------------------------------------------------------
+def bf16_round(a):
+    a = np.ascontiguousarray(a, np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(a.shape)
+
+
+def gru_forward_bf16(w, mel, state=None, seq_len=None):
+    mel = np.asarray(mel, np.float32)
+    b, t_len, _ = mel.shape
+    nl = len(w["layers"])
+    hdim = w["Wfc"].shape[0]
+    if state is None:
+        state = np.zeros((nl, b, hdim), np.float32)
+    h = [np.array(state[l], np.float64) for l in range(nl)]
+    if seq_len is None:
+        seq_len = np.full(b, t_len, np.int64)
+    seq_len = np.asarray(seq_len)
+    wq = [dict(Wg=bf16_round(l["Wg"]).astype(np.float64), Wc=bf16_round(l["Wc"]).astype(np.float64),
+               bg=l["bg"].astype(np.float64), bc=l["bc"].astype(np.float64)) for l in w["layers"]]
+    wfc = bf16_round(w["Wfc"]).astype(np.float64)
+    top = np.zeros((b, t_len, hdim), np.float64)
+    for t in range(t_len):
+        live = (t < seq_len)[:, None]
+        x = bf16_round(mel[:, t, :]).astype(np.float64)
+        for l in range(nl):
+            lay = wq[l]
+            i_l = x.shape[1]
+            hb = bf16_round(h[l].astype(np.float32)).astype(np.float64)
+            g = _sigmoid(x @ lay["Wg"][:i_l] + hb @ lay["Wg"][i_l:] + lay["bg"])
+            r, u = g[:, :hdim], g[:, hdim:]
+            rh = bf16_round((r * h[l]).astype(np.float32)).astype(np.float64)
+            c = np.tanh(x @ lay["Wc"][:i_l] + rh @ lay["Wc"][i_l:] + lay["bc"])
+            hn = u * h[l] + (1.0 - u) * c
+            h[l] = np.where(live, hn, h[l])
+            x = bf16_round(h[l].astype(np.float32)).astype(np.float64)       # next layer's input
+            if l == nl - 1:
+                top[:, t, :] = np.where(live, hn, 0.0)
+    logits = bf16_round(top.reshape(-1, hdim).astype(np.float32)).astype(np.float64) @ wfc + w["bfc"].astype(np.float64)
+    return logits.reshape(b, t_len, -1), np.stack(h)
