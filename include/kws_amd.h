@@ -131,6 +131,22 @@ int kws_ctc_predict(const int32_t* words, const int32_t* counts, int B, int max_
 int kws_vad(const float* pcm, int B, int N, float thres, uint8_t* speech, float* abs_sum_or_null,
             void* stream);
 
+/* PCM -> mel front-end of the deploy graph (models/rnn_ctc.py:134-149, utils/stft.py:27-81): frames of
+ * fft_size samples every hop_size (no padding, no window), |rfft|, projection on librosa.filters.mel(sr, n_fft,
+ * n_mels, fmin, fmax) (Slaney scale, area-normalised).  pcm [B,N] f32 -> mel [B,T,n_mel], T = 1+(N-fft)/hop
+ * (kws_frontend_frames).  fft_size must be a multiple of 16. */
+typedef struct kws_frontend_config {
+    int32_t samplerate, fft_size, hop_size, n_mel;
+    float fmin, fmax;
+} kws_frontend_config;
+typedef struct kws_frontend* kws_frontend_handle;
+int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out);
+int kws_frontend_destroy(kws_frontend_handle h);
+int kws_frontend_frames(const kws_frontend_config* cfg, int n_samples);
+int kws_frontend_run(kws_frontend_handle h, const float* pcm, int B, int n_samples, float* mel, void* stream);
+/* Copies the fp32 mel basis [n_mel, fft/2+1] (host memory) the handle was built with -- for inspection/tests. */
+int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host);
+
 /* OctbitMatMul: out[A,N] = (sum_k u8(x)[a,k] * Wq[n,k] - signed*bias[n]) * scale_w * s_x.
  *   x [A,K] f32, Wq [N,K] s8 (pre-transposed), bias [N] f32, out [A,N] f32.  K % 64 == 0, scale_w > 0.
  *   per_row_scale = 0: one dynamic activation range over the whole x (the reference op, whose A is

@@ -22,6 +22,11 @@ class KwsConfig(ctypes.Structure):
                 ("value_clip", ctypes.c_float), ("precision", ctypes.c_int32)]
 
 
+class KwsFrontendConfig(ctypes.Structure):
+    _fields_ = [("samplerate", ctypes.c_int32), ("fft_size", ctypes.c_int32), ("hop_size", ctypes.c_int32),
+                ("n_mel", ctypes.c_int32), ("fmin", ctypes.c_float), ("fmax", ctypes.c_float)]
+
+
 class KwsError(RuntimeError):
     """Base of the errors the C ABI reports."""
 
@@ -53,6 +58,11 @@ _SIGNATURES = {
     "kws_ctc_decode": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp]),
     "kws_ctc_predict": (_i, [_vp, _vp, _i, _i, ctypes.c_char_p, _vp, _vp]),
     "kws_vad": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp]),
+    "kws_frontend_create": (_i, [ctypes.POINTER(KwsFrontendConfig), ctypes.POINTER(_vp)]),
+    "kws_frontend_destroy": (_i, [_vp]),
+    "kws_frontend_frames": (_i, [ctypes.POINTER(KwsFrontendConfig), _i]),
+    "kws_frontend_run": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "kws_frontend_mel_basis": (_i, [_vp, _vp]),
     "kws_octbit_matmul": (_i, [_vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kws_octbit_quantize": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
 }

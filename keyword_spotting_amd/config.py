@@ -12,6 +12,8 @@ class Config(object):
         self.hop_size = 160                                 # :58
         self.samplerate = 16000                             # :59
         self.n_mel = 40                                     # :63 (60 in the repo file)
+        self.fmin = 300                                     # :64
+        self.fmax = 8000                                    # :65
         self.num_layers = 2                                 # :76
         self.value_clip = -1.0                              # :80
         self.use_relu = False                               # :83

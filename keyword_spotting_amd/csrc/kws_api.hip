@@ -65,7 +65,45 @@ struct kws_model {
     std::vector<int32_t> launches;
 };
 
+struct kws_frontend {
+    kws_frontend_config cfg;
+    float* d_tables = nullptr;
+    size_t dft_off = 0, melw_off = 0;
+    int nf_tiles = 0, mel_tiles = 0;
+    std::vector<float> basis;      // [n_mel][fft/2+1]
+};
+
 namespace {
+
+// librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm=1) restated (the reference calls it at
+// models/rnn_ctc.py:139-144; librosa itself is not available offline): Slaney mel scale -- linear below 1 kHz
+// (200/3 Hz per mel), logarithmic above (step ln(6.4)/27) -- triangular filters, each scaled by 2/(f_hi - f_lo).
+double hz_to_mel_slaney(double f) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz_slaney(double m) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+std::vector<float> slaney_mel_basis(int sr, int n_fft, int n_mels, double fmin, double fmax) {
+    const int nf = n_fft / 2 + 1;
+    std::vector<double> mel_f(n_mels + 2);
+    const double m_lo = hz_to_mel_slaney(fmin), m_hi = hz_to_mel_slaney(fmax);
+    for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz_slaney(m_lo + (m_hi - m_lo) * i / (n_mels + 1));
+    std::vector<float> w((size_t)n_mels * nf, 0.f);
+    for (int i = 0; i < n_mels; ++i) {
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int k = 0; k < nf; ++k) {
+            const double fk = (double)sr / 2.0 * k / (nf - 1);
+            const double lower = (fk - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+            const double upper = (mel_f[i + 2] - fk) / (mel_f[i + 2] - mel_f[i + 1]);
+            const double v = std::max(0.0, std::min(lower, upper));
+            w[(size_t)i * nf + k] = (float)(v * enorm);
+        }
+    }
+    return w;
+}
 
 bool config_ok(const kws_config* c, int* code) {
     if (!c) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "config is null"); return false; }
@@ -467,6 +505,98 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         }
 #endif
     }
+    return KWS_OK;
+}
+
+int kws_frontend_frames(const kws_frontend_config* cfg, int n_samples) {
+    if (!cfg || cfg->fft_size <= 0 || cfg->hop_size <= 0 || n_samples < cfg->fft_size) return 0;
+    return 1 + (n_samples - cfg->fft_size) / cfg->hop_size;
+}
+
+int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out) {
+    if (!out) return fail(KWS_ERR_INVALID_ARGUMENT, "out handle pointer is null");
+    *out = nullptr;
+    if (!cfg) return fail(KWS_ERR_INVALID_ARGUMENT, "config is null");
+    if (cfg->fft_size < 16 || cfg->fft_size > 4096 || cfg->fft_size % 16 != 0)
+        return fail(KWS_ERR_UNSUPPORTED, "fft_size=%d must be a multiple of 16 in [16,4096]", cfg->fft_size);
+    if (cfg->hop_size < 1 || cfg->n_mel < 1 || cfg->n_mel > 64 || cfg->samplerate < 1)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "bad hop_size/n_mel/samplerate (%d/%d/%d)", cfg->hop_size, cfg->n_mel, cfg->samplerate);
+    if (!(cfg->fmin >= 0.f) || !(cfg->fmax > cfg->fmin) || cfg->fmax > cfg->samplerate / 2.0f + 1e-3f)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "need 0 <= fmin < fmax <= sr/2");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(KWS_ERR_NO_DEVICE, "no HIP device visible");
+    kws_frontend* f = new (std::nothrow) kws_frontend();
+    if (!f) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
+    f->cfg = *cfg;
+    const int N = cfg->fft_size, NF = N / 2 + 1, KC4 = N / 16;
+    f->nf_tiles = (NF + 15) / 16;
+    f->mel_tiles = (cfg->n_mel + 15) / 16;
+    f->basis = slaney_mel_basis(cfg->samplerate, N, cfg->n_mel, cfg->fmin, cfg->fmax);
+    std::vector<float> host;
+    f->dft_off = 0;
+    host.resize((size_t)f->nf_tiles * 2 * KC4 * 64 * 4, 0.f);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int tile = 0; tile < f->nf_tiles; ++tile)
+        for (int cs = 0; cs < 2; ++cs)
+            for (int k4 = 0; k4 < KC4; ++k4)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int g = lane >> 4, i = lane & 15;
+                        const int bin = 16 * tile + i, n = 4 * (4 * k4 + e) + g;
+                        float v = 0.f;
+                        if (bin < NF) {
+                            const double ang = two_pi * (double)(((long long)bin * n) % N) / N;
+                            v = (float)(cs == 0 ? std::cos(ang) : std::sin(ang));
+                        }
+                        host[((((size_t)(tile * 2 + cs) * KC4 + k4) * 64 + lane) * 4) + e] = v;
+                    }
+    f->melw_off = host.size();
+    host.resize(host.size() + (size_t)f->mel_tiles * 4 * f->nf_tiles * 64, 0.f);
+    for (int mt = 0; mt < f->mel_tiles; ++mt)
+        for (int kc = 0; kc < 4 * f->nf_tiles; ++kc)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int g = lane >> 4, i = lane & 15;
+                const int bin = 16 * (kc / 4) + 4 * g + (kc % 4), m = 16 * mt + i;
+                host[f->melw_off + ((size_t)mt * 4 * f->nf_tiles + kc) * 64 + lane] =
+                    (bin < NF && m < cfg->n_mel) ? f->basis[(size_t)m * NF + bin] : 0.f;
+            }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_tables), host.size() * sizeof(float));
+    if (e != hipSuccess) { delete f; return hip_fail(e, "hipMalloc(frontend tables)"); }
+    e = hipMemcpy(f->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { hipFree(f->d_tables); delete f; return hip_fail(e, "hipMemcpy(frontend tables)"); }
+    *out = f;
+    return KWS_OK;
+}
+
+int kws_frontend_destroy(kws_frontend_handle h) {
+    if (!h) return KWS_OK;
+    hipDeviceSynchronize();
+    if (h->d_tables) hipFree(h->d_tables);
+    delete h;
+    return KWS_OK;
+}
+
+int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host) {
+    if (!h || !basis_host) return fail(KWS_ERR_INVALID_ARGUMENT, "null argument");
+    memcpy(basis_host, h->basis.data(), h->basis.size() * sizeof(float));
+    return KWS_OK;
+}
+
+int kws_frontend_run(kws_frontend_handle h, const float* pcm, int B, int n_samples, float* mel, void* stream) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (B < 0 || n_samples < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative dimension");
+    const int T = kws_frontend_frames(&h->cfg, n_samples);
+    if (B == 0 || T == 0) return KWS_OK;
+    if (!pcm || !mel) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (B > 65535) return fail(KWS_ERR_UNSUPPORTED, "B=%d exceeds the grid limit 65535", B);
+    kws::FrontendParams p;
+    p.pcm = pcm; p.mel = mel;
+    p.dft = h->d_tables + h->dft_off; p.melw = h->d_tables + h->melw_off;
+    p.n_samples = n_samples; p.T = T; p.fft = h->cfg.fft_size; p.hop = h->cfg.hop_size; p.n_mel = h->cfg.n_mel;
+    p.nf_tiles = h->nf_tiles; p.mel_tiles = h->mel_tiles;
+    hipError_t e = kws::launch_mel_frontend(p, B, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch mel_frontend");
     return KWS_OK;
 }
 

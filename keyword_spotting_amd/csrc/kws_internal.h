@@ -62,6 +62,16 @@ struct GruBf16Params {
 bool gru_bf16_supported(int hidden, int n_mel, int layers);
 hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st);
 
+// PCM -> mel front-end (frontend_kernels.hip)
+struct FrontendParams {
+    const float* pcm;    // [B, n_samples]
+    float* mel;          // [B, T, n_mel]
+    const float* dft;    // [nf_tiles][cos|sin][fft/16][64][4]  A fragments, k map n = 4*kc + g
+    const float* melw;   // [mel_tiles][4*nf_tiles][64]         A fragments of the mel basis, xl k map over bins
+    int n_samples, T, fft, hop, n_mel, nf_tiles, mel_tiles;
+};
+hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st);
+
 // launchers (gru_kernels.hip)
 bool gru_resident_supported(int hidden, int in_dim, bool first);
 int gru_resident_kcx(int in_dim, bool first);

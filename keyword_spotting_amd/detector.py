@@ -105,6 +105,28 @@ class HotwordDetector(object):
             self.clean_state(b)                                      # :208
         return fired
 
+    def feed_pcm(self, pcm_chunk, frontend):
+        """The reference's real input contract (detector.py:162-193): raw PCM chunks [B,n].  Prepends the
+        carried tail (:179), keeps the new tail (:181-183), runs the in-graph front-end
+        (models/rnn_ctc.py:134-149, here `frontend` = keyword_spotting_amd.frontend.MelFrontend) and the
+        loop body; VAD looks at the newly captured chunk only (:168)."""
+        chunk = torch.as_tensor(pcm_chunk, dtype=torch.float32)
+        if chunk.dim() == 1:
+            chunk = chunk.unsqueeze(0)
+        chunk = chunk.to(self.model.device)
+        if not hasattr(self, "res"):
+            self.res = chunk[:, :0]                                   # :125
+        data = torch.cat([self.res, chunk], 1)                        # :179
+        fft, hop = self.config.fft_size, self.config.hop_size
+        n = int(data.shape[1])
+        if n < fft:                                                   # not a full frame yet: carry everything
+            self.res = data
+            return []
+        keep = (n - fft) % hop + (fft - hop)                          # :181-182
+        self.res = data[:, n - keep:].contiguous()                    # :183
+        mel = frontend.forward(data.contiguous())
+        return self.feed(mel, pcm_chunk=chunk)
+
     def test2(self, mel, chunk_frames):
         """detector.py:254-289: replay whole utterances [B,T,n_mel] in chunks with the state threaded
         through, accumulate the softmax, decode once with ctc_decode.  Returns (words, counts)."""
