@@ -65,6 +65,12 @@ struct kws_model {
     std::vector<int32_t> launches;
 };
 
+struct kws_window {
+    int B = 0, nq = 0, tmax = 0, C = 0;
+    float* ring = nullptr;
+    int *lens = nullptr, *head = nullptr, *count = nullptr;
+};
+
 struct kws_frontend {
     kws_frontend_config cfg;
     float* d_tables = nullptr;
@@ -505,6 +511,60 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         }
 #endif
     }
+    return KWS_OK;
+}
+
+int kws_window_create(int B, int max_chunks, int max_frames, int C, kws_window_handle* out) {
+    if (!out) return fail(KWS_ERR_INVALID_ARGUMENT, "out handle pointer is null");
+    *out = nullptr;
+    if (B < 1 || max_chunks < 1 || max_frames < 1 || C < 3 || C > 64)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "bad window shape B=%d chunks=%d frames=%d C=%d", B, max_chunks, max_frames, C);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(KWS_ERR_NO_DEVICE, "no HIP device visible");
+    kws_window* wnd = new (std::nothrow) kws_window();
+    if (!wnd) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
+    wnd->B = B; wnd->nq = max_chunks; wnd->tmax = max_frames; wnd->C = C;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&wnd->ring), (size_t)B * max_chunks * max_frames * C * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->lens), (size_t)B * max_chunks * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->head), (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->count), (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = kws::launch_window_reset(B, wnd->head, wnd->count, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { kws_window_destroy(wnd); return hip_fail(e, "kws_window_create"); }
+    *out = wnd;
+    return KWS_OK;
+}
+
+int kws_window_destroy(kws_window_handle h) {
+    if (!h) return KWS_OK;
+    hipDeviceSynchronize();
+    if (h->ring) hipFree(h->ring);
+    if (h->lens) hipFree(h->lens);
+    if (h->head) hipFree(h->head);
+    if (h->count) hipFree(h->count);
+    delete h;
+    return KWS_OK;
+}
+
+int kws_window_step(kws_window_handle h, const float* softmax, int T, const uint8_t* clear_before, const char* label,
+                    float thres, int32_t* hit, uint8_t* restart, void* stream) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (T < 0 || T > h->tmax) return fail(KWS_ERR_INVALID_ARGUMENT, "T=%d outside [0,%d]", T, h->tmax);
+    if (!hit || (!softmax && T > 0) || !label) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    const int n = (int)strlen(label);
+    if (n > 16) return fail(KWS_ERR_INVALID_ARGUMENT, "label longer than 16 digits");
+    kws::WindowParams p;
+    memset(&p, 0, sizeof(p));
+    for (int i = 0; i < n; ++i) {
+        if (label[i] < '1' || label[i] > '9') return fail(KWS_ERR_INVALID_ARGUMENT, "label must be digits 1..9, got '%s'", label);
+        p.label[i] = label[i] - '0';
+    }
+    p.label_len = n;
+    p.ring = h->ring; p.lens = h->lens; p.head = h->head; p.count = h->count;
+    p.softmax = softmax; p.clear_before = clear_before; p.hit = hit; p.restart = restart;
+    p.thres = thres; p.B = h->B; p.T = T; p.C = h->C; p.nq = h->nq; p.tmax = h->tmax;
+    hipError_t e = kws::launch_window_step(p, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch window_step");
     return KWS_OK;
 }
 

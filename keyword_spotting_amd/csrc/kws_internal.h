@@ -62,6 +62,24 @@ struct GruBf16Params {
 bool gru_bf16_supported(int hidden, int n_mel, int layers);
 hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st);
 
+// decode window of the stream manager (stream_kernels.hip)
+struct WindowParams {
+    float* ring;              // [B][nq][tmax][C]
+    int* lens;                // [B][nq]
+    int* head;                // [B]
+    int* count;               // [B]
+    const float* softmax;     // [B][T][C] this chunk
+    const uint8_t* clear_before;  // [B] or null
+    int32_t* hit;             // [B]
+    uint8_t* restart;         // [B] or null
+    int32_t label[16];
+    int label_len;
+    float thres;
+    int B, T, C, nq, tmax;
+};
+hipError_t launch_window_step(const WindowParams& p, hipStream_t st);
+hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st);
+
 // PCM -> mel front-end (frontend_kernels.hip)
 struct FrontendParams {
     const float* pcm;    // [B, n_samples]

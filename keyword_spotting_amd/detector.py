@@ -143,3 +143,77 @@ class HotwordDetector(object):
             pos += n
         accu = torch.cat(parts, 1)
         return decode_batch(_lib.DECODE, accu, None, 3, 0.5, 0.2)    # :288
+
+
+class StreamManager(object):
+    """The same loop with every per-stream decision on the device: kws_vad -> reset mask ->
+    kws_step -> kws_window_step (15-chunk softmax ring, windowed ctc_decode2 + ctc_predict, trigger -> clear +
+    restart).  No per-stream Python; B in the thousands costs four launches per chunk.  Results are identical to
+    HotwordDetector (tests/test_gpu_detector.py)."""
+
+    def __init__(self, model, batch, window_chunks=15, max_frames=32, vad_thres=30, label=None, decode_thres=0.4):
+        import ctypes
+        self.model, self.config, self.batch = model, model.config, int(batch)
+        self.vad_thres, self.decode_thres = vad_thres, decode_thres
+        self.label = (label or self.config.label_seqs).encode()
+        self._lib = _lib.load()
+        self._win = ctypes.c_void_p()
+        with torch.cuda.device(model.device):
+            _lib.check(self._lib.kws_window_create(self.batch, int(window_chunks), int(max_frames),
+                                                   self.config.num_classes, ctypes.byref(self._win)))
+        dev = model.device
+        self.state = model.zero_state(self.batch)
+        self.restart = torch.zeros(self.batch, dtype=torch.uint8, device=dev)     # reset requested by a trigger
+        self.hit = torch.zeros(self.batch, dtype=torch.int32, device=dev)
+        self.softmax = None
+        self.res = None
+
+    def close(self):
+        if getattr(self, "_win", None) is not None and self._win.value:
+            self._lib.kws_window_destroy(self._win)
+            self._win.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, mel_chunk, pcm_chunk=None, speech=None):
+        """-> hit [B] int32 device tensor (1 = keyword detected on this chunk)."""
+        mel = torch.as_tensor(mel_chunk)
+        if mel.dim() == 2:
+            mel = mel.unsqueeze(0)
+        dev = self.model.device
+        if speech is None and pcm_chunk is not None:
+            pcm = torch.as_tensor(pcm_chunk)
+            speech = _vad(pcm if pcm.dim() == 2 else pcm.unsqueeze(0), self.vad_thres)
+        if speech is None:
+            silent = torch.zeros(self.batch, dtype=torch.uint8, device=dev)
+        else:
+            silent = (torch.as_tensor(speech).to(dev) == 0).to(torch.uint8)
+        reset = torch.maximum(self.restart, silent)                       # detector.py:171-177 and :208
+        r = self.model.forward(mel, self.state, reset_mask=reset, want_logits=False, want_softmax=True,
+                               state_out=self.state)
+        sm = r["softmax"]
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.kws_window_step(self._win, _lib.ptr(sm), int(sm.shape[1]), _lib.ptr(silent), self.label,
+                                                 float(self.decode_thres), _lib.ptr(self.hit), _lib.ptr(self.restart),
+                                                 _lib.current_stream_ptr()))
+        return self.hit
+
+    def feed_pcm(self, pcm_chunk, frontend):
+        chunk = torch.as_tensor(pcm_chunk, dtype=torch.float32)
+        if chunk.dim() == 1:
+            chunk = chunk.unsqueeze(0)
+        chunk = chunk.to(self.model.device)
+        data = chunk if self.res is None else torch.cat([self.res, chunk], 1)
+        fft, hop = self.config.fft_size, self.config.hop_size
+        n = int(data.shape[1])
+        if n < fft:
+            self.res = data
+            self.hit.zero_()
+            return self.hit
+        keep = (n - fft) % hop + (fft - hop)
+        self.res = data[:, n - keep:].contiguous()
+        return self.feed(frontend.forward(data.contiguous()), pcm_chunk=chunk)
