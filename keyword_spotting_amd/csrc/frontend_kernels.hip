@@ -5,9 +5,12 @@
 //
 // One workgroup = 16 consecutive frames of one stream.  The DFT is a dense fp32 contraction on
 // v_mfma_f32_16x16x4_f32 with D[bin][frame]: A = cos / sin rows streamed from L2 in group-of-4 fragment order,
-// B = the frames, read from a skewed LDS copy (row stride 401 floats: conflict-free column reads).  Magnitudes
-// land in the xl layout (kws_internal.h), which is directly the B operand of the mel projection -- no transpose.
-// Correctness-first: a radix-16x25 two-stage factorisation would cut the matrix work ~5x.
+// B = the frames.  Real input: with e[n] = x[n] + x[N-n], o[n] = x[n] - x[N-n] (0 < n < N/2), e[0] = x[0],
+// e[N/2] = x[N/2]:   Re X[k] = sum_{n<=N/2} e[n] cos(2 pi k n / N),   Im X[k] = -sum_{n<N/2} o[n] sin(2 pi k n / N)
+// so both contractions run over N/2 (+1) samples instead of N -- half the MFMAs; the fold happens while the
+// window is staged into LDS (row stride odd: conflict-free column reads).  Magnitudes land in the xl layout
+// (kws_internal.h), which is directly the B operand of the mel projection -- no transpose.
+// A radix-16x25 two-stage factorisation would cut the matrix work a further ~2.5x.
 #include "gru_device.h"
 
 namespace kws {
@@ -17,31 +20,43 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, g = lane >> 4, f = lane & 15;
     const int t0 = blockIdx.x * 16, b = blockIdx.y;
-    const int N = p.fft, HOP = p.hop, KC4 = p.fft / 16, NFT = p.nf_tiles;
-    const int stride = p.fft + 1;
+    const int N = p.fft, HOP = p.hop, NFT = p.nf_tiles;
+    const int NH = N / 2;                    // folded length (cos part also uses sample NH)
+    const int KC4 = p.kc4;                   // groups of 16 folded samples: ceil((NH+1)/16)
+    const int stride = 16 * KC4 + 1;         // odd
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem);                                   // [16][fft+1]
-    f32x4* magbuf = reinterpret_cast<f32x4*>(xs + ((16 * stride + 3) & ~3));      // [NFT][64]
+    float* xe = reinterpret_cast<float*>(smem);                                   // [16][stride] even part
+    float* xo = xe + 16 * stride;                                                  // [16][stride] odd part
+    f32x4* magbuf = reinterpret_cast<f32x4*>(xo + ((16 * stride + 3) & ~3));      // [NFT][64]
 
     const float* pcm = p.pcm + (size_t)b * p.n_samples;
-    for (int i = tid; i < 16 * N; i += 256) {
-        const int fr = i / N, n = i - fr * N;
+    for (int i = tid; i < 16 * 16 * KC4; i += 256) {
+        const int fr = i / (16 * KC4), n = i - fr * (16 * KC4);
         const int t = t0 + fr;
-        xs[fr * stride + n] = t < p.T ? pcm[(size_t)t * HOP + n] : 0.f;
+        float e = 0.f, o = 0.f;
+        if (t < p.T && n <= NH) {
+            const float* x = pcm + (size_t)t * HOP;
+            const float a = x[n];
+            if (n == 0 || n == NH) { e = a; }
+            else { const float c = x[N - n]; e = a + c; o = a - c; }
+        }
+        xe[fr * stride + n] = e;
+        xo[fr * stride + n] = o;
     }
     __syncthreads();
 
-    // DFT: tiles w, w+4, w+8, w+12
+    // DFT over the folded samples: tiles w, w+4, w+8, w+12
     f32x4 re[4], im[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { re[j] = splat4(0.f); im[j] = splat4(0.f); }
     const f32x4* dft = reinterpret_cast<const f32x4*>(p.dft);                      // [NFT][2][KC4][64]
-    const float* xrow = xs + f * stride + g;
+    const float* erow = xe + f * stride + g;
+    const float* orow = xo + f * stride + g;
     for (int k4 = 0; k4 < KC4; ++k4) {
-        f32x4 xb;
+        f32x4 eb, ob;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xb[e] = xrow[16 * k4 + 4 * e];
+        for (int e = 0; e < 4; ++e) { eb[e] = erow[16 * k4 + 4 * e]; ob[e] = orow[16 * k4 + 4 * e]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int tile = w + 4 * j;
@@ -50,8 +65,8 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
                 const f32x4 as = dft[((size_t)(tile * 2 + 1) * KC4 + k4) * 64 + lane];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    re[j] = mfma4(ac[e], xb[e], re[j]);
-                    im[j] = mfma4(as[e], xb[e], im[j]);
+                    re[j] = mfma4(ac[e], eb[e], re[j]);
+                    im[j] = mfma4(as[e], ob[e], im[j]);
                 }
             }
         }
@@ -88,7 +103,8 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
 }
 
 hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st) {
-    const size_t lds = (size_t)((16 * (p.fft + 1) + 3) & ~3) * 4 + (size_t)p.nf_tiles * 64 * 16;
+    const int stride = 16 * p.kc4 + 1;
+    const size_t lds = (size_t)(16 * stride + ((16 * stride + 3) & ~3)) * 4 + (size_t)p.nf_tiles * 64 * 16;
     static size_t granted = 0;
     if (lds > granted) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_frontend_kernel),

@@ -75,7 +75,7 @@ struct kws_frontend {
     kws_frontend_config cfg;
     float* d_tables = nullptr;
     size_t dft_off = 0, melw_off = 0;
-    int nf_tiles = 0, mel_tiles = 0;
+    int nf_tiles = 0, mel_tiles = 0, kc4 = 0;
     std::vector<float> basis;      // [n_mel][fft/2+1]
 };
 
@@ -588,7 +588,8 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
     kws_frontend* f = new (std::nothrow) kws_frontend();
     if (!f) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
     f->cfg = *cfg;
-    const int N = cfg->fft_size, NF = N / 2 + 1, KC4 = N / 16;
+    const int N = cfg->fft_size, NF = N / 2 + 1, KC4 = (N / 2 + 1 + 15) / 16;   // folded samples 0..N/2
+    f->kc4 = KC4;
     f->nf_tiles = (NF + 15) / 16;
     f->mel_tiles = (cfg->n_mel + 15) / 16;
     f->basis = slaney_mel_basis(cfg->samplerate, N, cfg->n_mel, cfg->fmin, cfg->fmax);
@@ -604,7 +605,8 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
                         const int g = lane >> 4, i = lane & 15;
                         const int bin = 16 * tile + i, n = 4 * (4 * k4 + e) + g;
                         float v = 0.f;
-                        if (bin < NF) {
+                        // cos rows use folded samples 0..N/2, sin rows 1..N/2-1 (sin vanishes at 0 and N/2)
+                        if (bin < NF && n <= N / 2 && !(cs == 1 && (n == 0 || n == N / 2))) {
                             const double ang = two_pi * (double)(((long long)bin * n) % N) / N;
                             v = (float)(cs == 0 ? std::cos(ang) : std::sin(ang));
                         }
@@ -654,7 +656,7 @@ int kws_frontend_run(kws_frontend_handle h, const float* pcm, int B, int n_sampl
     p.pcm = pcm; p.mel = mel;
     p.dft = h->d_tables + h->dft_off; p.melw = h->d_tables + h->melw_off;
     p.n_samples = n_samples; p.T = T; p.fft = h->cfg.fft_size; p.hop = h->cfg.hop_size; p.n_mel = h->cfg.n_mel;
-    p.nf_tiles = h->nf_tiles; p.mel_tiles = h->mel_tiles;
+    p.nf_tiles = h->nf_tiles; p.mel_tiles = h->mel_tiles; p.kc4 = h->kc4;
     hipError_t e = kws::launch_mel_frontend(p, B, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "launch mel_frontend");
     return KWS_OK;

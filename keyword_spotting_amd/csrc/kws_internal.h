@@ -84,9 +84,9 @@ hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st);
 struct FrontendParams {
     const float* pcm;    // [B, n_samples]
     float* mel;          // [B, T, n_mel]
-    const float* dft;    // [nf_tiles][cos|sin][fft/16][64][4]  A fragments, k map n = 4*kc + g
+    const float* dft;    // [nf_tiles][cos|sin][kc4][64][4]  A fragments over the FOLDED samples n = 0..fft/2, k map n = 4*kc + g
     const float* melw;   // [mel_tiles][4*nf_tiles][64]         A fragments of the mel basis, xl k map over bins
-    int n_samples, T, fft, hop, n_mel, nf_tiles, mel_tiles;
+    int n_samples, T, fft, hop, n_mel, nf_tiles, mel_tiles, kc4;
 };
 hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st);
 
