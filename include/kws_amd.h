@@ -81,14 +81,15 @@ size_t kws_weights_nbytes(const kws_config* cfg);
 int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, kws_handle* out);
 int kws_destroy(kws_handle h);
 
-/* Kernel family used by kws_step: AUTO picks the register-resident kernels when the shape allows
- * (H == 128, I <= 128), else the generic ones.  RESIDENT on an unsupported shape -> KWS_ERR_UNSUPPORTED. */
+/* Kernel family used by kws_step (fp32): AUTO picks the register-resident kernels when the shape allows
+ * (hidden == 128 and n_mel in {40, 60}), else the generic ones (hidden 64/128/256, any n_mel).
+ * RESIDENT on an unsupported shape -> KWS_ERR_UNSUPPORTED.  Ignored by the bf16 stack. */
 int kws_set_kernel(kws_handle h, int kind);
 /* Pre-sizes the inter-layer scratch for B streams x T frames so kws_step never allocates. */
 int kws_reserve(kws_handle h, int B, int T);
 
 /* Advances B independent streams by T frames (one 10 ms hop each).
- *   mel        [B,T,I]  f32                          model/inputX:0 (mel variant), batch-major
+ *   mel        [B,T,I]  f32, 16-byte aligned         model/inputX:0 (mel variant), batch-major
  *   state_in   [L,B,H]  f32                          model/rnn_initial_states:0
  *   logits     [B,T,C]  f32   out, may be NULL       model/logit:0
  *   softmax    [B,T,C]  f32   out, may be NULL       model/softmax:0

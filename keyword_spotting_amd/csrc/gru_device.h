@@ -169,6 +169,23 @@ __device__ __forceinline__ void epilogue_fold(const EpilogueLds& e, int t, int l
     }
 }
 
+// the same fold in two halves, so the LDS round trip can sit behind independent MFMAs
+struct FoldRegs { f32x4 v[4]; };
+__device__ __forceinline__ void epilogue_fold_load(const EpilogueLds& e, int lane, FoldRegs& r) {
+    if (lane < 32) {
+        const int s = lane >> 1, half = lane & 1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) r.v[w] = *reinterpret_cast<const f32x4*>(e.pstage + (w * 16 + s) * 8 + 4 * half);
+    }
+}
+__device__ __forceinline__ void epilogue_fold_store(const EpilogueLds& e, int t, int lane, const FoldRegs& r) {
+    if (lane < 32) {
+        const int s = lane >> 1, half = lane & 1;
+        const f32x4 v = ((r.v[0] + r.v[1]) + r.v[2]) + r.v[3];        // same order as epilogue_fold
+        *reinterpret_cast<f32x4*>(e.lring + (((t & (kRingFrames - 1)) * 16 + s) * 8 + 4 * half)) = v;
+    }
+}
+
 // flush frames [t0, t0+n) of the ring; called by all four waves of the group together
 __device__ __forceinline__ void epilogue_flush(const GruLayerParams& p, const EpilogueLds& e, int group, int t0,
                                                int n, int w, int lane, bool final_flush) {

@@ -405,12 +405,15 @@ gru_layer_resident(const GruLayerParams p) {
 #endif
         hb_a = hbuf[0 * 64 + lane];
         hb_b = hbuf[1 * 64 + lane];
+        FoldRegs fold;
+        const bool folder = LAST && w == (t & 3);
+        if (folder) epilogue_fold_load(epi, lane, fold);      // LDS reads in flight behind the MFMAs below
         __builtin_amdgcn_sched_barrier(0);
         static_for<NPRE, NCX>(cand_x_mfma);   // the rest of frame t+1's candidate x-part hides the hbuf read
         __builtin_amdgcn_sched_barrier(0);
 #ifndef KWS_ABL_NOFLUSH
         if (LAST) {
-            if (w == (t & 3)) epilogue_fold(epi, t, lane);
+            if (folder) epilogue_fold_store(epi, t, lane, fold);
             if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
                 const int t0 = t & ~(kRingFrames - 1);
                 lds_barrier();                       // the fold of frame t is visible to every wave

@@ -37,7 +37,7 @@ int hip_fail(hipError_t e, const char* what) {
 struct LayerDev {
     int in_dim;
     // offsets (floats) into the single device allocation
-    size_t wx_res, wh_res, wx_gen, wh_gen, bias;
+    size_t wx_res, wx_gen, wh_gen, bias;   // wx_res: first-layer x-part, interleaved k map (resident kernel)
     int kcx_res, kcx_gen;
     bool resident_ok;
 };
@@ -208,8 +208,7 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
         L.bias = reserve(3 * (size_t)H);
         for (int j = 0; j < 2 * H; ++j) host[L.bias + j] = bg[j];
         for (int j = 0; j < H; ++j) host[L.bias + 2 * H + j] = bc[j];
-        // h-part, fragment-major [NT][3][KCH][64] (resident) and group-of-4 [NT][3][NT][64][4] (generic)
-        L.wh_res = reserve((size_t)NT * 3 * KCH * 64);
+        // h-part, group-of-4 fragments [NT][3][NT][64][4] (one dwordx4 = four k-chunks; both kernel families)
         L.wh_gen = reserve((size_t)NT * 3 * KCH * 64);
         for (int n = 0; n < NT; ++n)
             for (int q = 0; q < 3; ++q)
@@ -217,7 +216,6 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
                     for (int lane = 0; lane < 64; ++lane) {
                         const int g = lane >> 4, i = lane & 15;
                         const float v = wq(Wg, Wc, H, q, in + kmap_grouped(kc, g), n * 16 + i);
-                        host[L.wh_res + (((size_t)(n * 3 + q) * KCH + kc) * 64 + lane)] = v;
                         host[L.wh_gen + ((((size_t)(n * 3 + q) * NT + kc / 4) * 64 + lane) * 4 + kc % 4)] = v;
                     }
         // x-part

@@ -8,7 +8,6 @@
 namespace kws {
 
 constexpr int kStreamsPerGroup = 16;  // MFMA N dimension: one workgroup advances 16 streams
-constexpr int kFlushSteps = 4;        // logits are staged in LDS and flushed every 4 frames
 constexpr int kMaxClasses = 8;
 
 // One launch = one GRU layer over all T frames of the call, for every 16-stream group.
