@@ -134,6 +134,18 @@ def main():
                     "multi-process path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # not under torchrun: start one rank per GPU as CHILD processes (nothing here has touched the GPU yet)
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     from keyword_spotting_amd import get_config, sharding, weights
     from keyword_spotting_amd.rnn_ctc import DeployModel
