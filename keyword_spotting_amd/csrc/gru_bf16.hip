@@ -80,7 +80,10 @@ gru_stack_bf16(const GruBf16Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int c = KX0; c < KC0; ++c) asm volatile("" : "+a"(w0[j][0][c]));    // r-gate h-part of layer 0
+        for (int c = KX0; c < KC0; ++c) {
+            asm volatile("" : "+a"(w0[j][0][c]));                                // r-gate h-part of layer 0
+            if constexpr (NL > 1) asm volatile("" : "+a"(w0[j][1][c]));          // u-gate too in the skewed 2-layer loop
+        }
     asm volatile("s_nop 7" ::: "memory");
     const bf16x8 wfc = as_bf16x8(reinterpret_cast<const u32x4*>(p.wfc)[w * 64 + lane]);
     f32x4 bfc4 = splat4(0.f);
@@ -257,10 +260,167 @@ gru_stack_bf16(const GruBf16Params p) {
             epilogue_flush(p.epi, epi, group, t0, t - t0 + 1, w, lane, t == T - 1);
         }
     };
+    if constexpr (NL == 2) {
+        // ---- skewed two-layer loop: iteration i runs layer 0 on frame i+1 and layer 1 on frame i in the SAME two
+        // phases, so a frame costs 2 barriers and 2 LDS round trips instead of 4-5.  hb[0] = h0(i) is read once
+        // and serves both as layer 0's previous state and as layer 1's input.  Iterations i = -1 and i = T-1 run one
+        // of the layers on nothing: its `live` mask is off, so its state is left untouched (bitsel).
+        const f32x4* bl0 = reinterpret_cast<const f32x4*>(biasl);
+        const f32x4* bl1 = reinterpret_cast<const f32x4*>(biasl + 3 * H);
+        auto iteration = [&](int i, float4& fl_commit) {
+            // ---------------- phase 1: gates of both layers ----------------
+            bf16x8 xB[KX0], h0B[4], h1B[4];
+#pragma unroll
+            for (int c = 0; c < KX0; ++c) xB[c] = as_bf16x8(xsb[c * 64 + lane]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { h0B[m] = as_bf16x8(hb[(0 * 4 + m) * 64 + lane]); h1B[m] = as_bf16x8(hb[(1 * 4 + m) * 64 + lane]); }
+            f32x4 r0[2], u0[2], c0[2], r1[2], u1[2], c1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (2 * w + j) * 4 + g;
+                r0[j] = bl0[0 * 32 + o]; u0[j] = bl0[1 * 32 + o]; c0[j] = bl0[2 * 32 + o];
+                r1[j] = bl1[0 * 32 + o]; u1[j] = bl1[1 * 32 + o]; c1[j] = bl1[2 * 32 + o];
+            }
+            // layer 0, frame i+1: x-part (VGPR operands, builtin) then gate h-part (AGPR operands)
+#pragma unroll
+            for (int c = 0; c < KX0; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    r0[j] = mfma_bf16(w0[j][0][c], xB[c], r0[j]);
+                    u0[j] = mfma_bf16(w0[j][1][c], xB[c], u0[j]);
+                    c0[j] = mfma_bf16(w0[j][2][c], xB[c], c0[j]);
+                }
+            mfma_prefence(r0[0], u0[0], r0[1], u0[1]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    KWS_MFMA_BF16_A(r0[j], w0[j][0][KX0 + m], h0B[m]);
+                    KWS_MFMA_BF16_A(u0[j], w0[j][1][KX0 + m], h0B[m]);
+                }
+            // layer 1, frame i: x-part on h0(i) (the same registers), gate h-part on h1(i-1)
+            mfma_prefence(r1[0], u1[0], r1[1], u1[1]);
+            mfma_prefence(c1[0], c1[1]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    KWS_MFMA_BF16_A(r1[j], w1[j][0][m], h0B[m]);
+                    KWS_MFMA_BF16_A(u1[j], w1[j][1][m], h0B[m]);
+                    KWS_MFMA_BF16_A(c1[j], w1[j][2][m], h0B[m]);
+                }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    KWS_MFMA_BF16_A(r1[j], w1[j][0][4 + m], h1B[m]);
+                    KWS_MFMA_BF16_A(u1[j], w1[j][1][4 + m], h1B[m]);
+                }
+            mfma_fence(r0[0], u0[0], r0[1], u0[1]);
+            mfma_fence(r1[0], u1[0], r1[1], u1[1]);
+            // sigmoids: r first (feeds the exchange), then u
+            f32x4 rh0[2], rh1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 a = sigmoid2((f32x2){r0[j][2 * h2], r0[j][2 * h2 + 1]}) * (f32x2){hreg[0][j][2 * h2], hreg[0][j][2 * h2 + 1]};
+                    const f32x2 b2 = sigmoid2((f32x2){r1[j][2 * h2], r1[j][2 * h2 + 1]}) * (f32x2){hreg[1][j][2 * h2], hreg[1][j][2 * h2 + 1]};
+                    rh0[j][2 * h2] = a.x; rh0[j][2 * h2 + 1] = a.y;
+                    rh1[j][2 * h2] = b2.x; rh1[j][2 * h2 + 1] = b2.y;
+                }
+            }
+            rhb[(0 * 4 + w) * 64 + lane] = (u32x4){pack_bf16(rh0[0][0], rh0[0][1]), pack_bf16(rh0[0][2], rh0[0][3]),
+                                                    pack_bf16(rh0[1][0], rh0[1][1]), pack_bf16(rh0[1][2], rh0[1][3])};
+            rhb[(1 * 4 + w) * 64 + lane] = (u32x4){pack_bf16(rh1[0][0], rh1[0][1]), pack_bf16(rh1[0][2], rh1[0][3]),
+                                                    pack_bf16(rh1[1][0], rh1[1][1]), pack_bf16(rh1[1][2], rh1[1][3])};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 a = sigmoid2((f32x2){u0[j][2 * h2], u0[j][2 * h2 + 1]});
+                    const f32x2 b2 = sigmoid2((f32x2){u1[j][2 * h2], u1[j][2 * h2 + 1]});
+                    u0[j][2 * h2] = a.x; u0[j][2 * h2 + 1] = a.y;
+                    u1[j][2 * h2] = b2.x; u1[j][2 * h2 + 1] = b2.y;
+                }
+            }
+            lds_barrier();            // #1: both r(.)h visible; hb / xsb fully consumed
+            // ---------------- phase 2: candidates, state updates, dense ----------------
+            mfma_prefence(c0[0], c0[1]);
+            mfma_prefence(c1[0], c1[1]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const bf16x8 rB0 = as_bf16x8(rhb[(0 * 4 + m) * 64 + lane]);
+                const bf16x8 rB1 = as_bf16x8(rhb[(1 * 4 + m) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    c0[j] = mfma_bf16(w0[j][2][KX0 + m], rB0, c0[j]);
+                    KWS_MFMA_BF16_A(c1[j], w1[j][2][4 + m], rB1);
+                }
+            }
+            mfma_fence(c0[0], c0[1], c1[0], c1[1]);
+            const unsigned live0 = (i + 1 < T && i + 1 < len_s) ? 0xffffffffu : 0u;
+            const unsigned live1 = (i >= 0 && i < len_s) ? 0xffffffffu : 0u;
+            f32x4 hout[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    {
+                        const f32x2 c = tanh2((f32x2){c0[j][2 * h2], c0[j][2 * h2 + 1]});
+                        const f32x2 uu = {u0[j][2 * h2], u0[j][2 * h2 + 1]};
+                        const f32x2 hh = {hreg[0][j][2 * h2], hreg[0][j][2 * h2 + 1]};
+                        const f32x2 hn = (1.0f - uu) * c + uu * hh;
+                        hreg[0][j][2 * h2] = bitsel(live0, hn.x, hh.x);
+                        hreg[0][j][2 * h2 + 1] = bitsel(live0, hn.y, hh.y);
+                    }
+                    {
+                        const f32x2 c = tanh2((f32x2){c1[j][2 * h2], c1[j][2 * h2 + 1]});
+                        const f32x2 uu = {u1[j][2 * h2], u1[j][2 * h2 + 1]};
+                        const f32x2 hh = {hreg[1][j][2 * h2], hreg[1][j][2 * h2 + 1]};
+                        const f32x2 hn = (1.0f - uu) * c + uu * hh;
+                        hreg[1][j][2 * h2] = bitsel(live1, hn.x, hh.x);
+                        hreg[1][j][2 * h2 + 1] = bitsel(live1, hn.y, hh.y);
+                        hout[j][2 * h2] = bitsel(live1, hn.x, 0.f);
+                        hout[j][2 * h2 + 1] = bitsel(live1, hn.y, 0.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+                hb[(l * 4 + w) * 64 + lane] = (u32x4){pack_bf16(hreg[l][0][0], hreg[l][0][1]), pack_bf16(hreg[l][0][2], hreg[l][0][3]),
+                                                       pack_bf16(hreg[l][1][0], hreg[l][1][1]), pack_bf16(hreg[l][1][2], hreg[l][1][3])};
+            commit(fl_commit);        // x(i+2)
+            fetch(fl_commit, i + 4);
+            if (i >= 0) {
+                u32x4 hBv = (u32x4){pack_bf16(hout[0][0], hout[0][1]), pack_bf16(hout[0][2], hout[0][3]),
+                                    pack_bf16(hout[1][0], hout[1][1]), pack_bf16(hout[1][2], hout[1][3])};
+                asm volatile("s_nop 3" : "+v"(hBv));
+                const f32x4 accf = mfma_bf16(wfc, as_bf16x8(hBv), bfc4);
+                if (g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
+            }
+            lds_barrier();            // #2: h0(i+1), h1(i), x(i+2), partial logits visible
+            if (i >= 0) {
+                if (w == (i & 3)) epilogue_fold(epi, i, lane);
+                if (((i + 1) & (kRingFrames - 1)) == 0 || i == T - 1) {
+                    const int t0 = i & ~(kRingFrames - 1);
+                    lds_barrier();
+                    epilogue_flush(p.epi, epi, group, t0, i - t0 + 1, w, lane, i == T - 1);
+                }
+            }
+        };
+        // prologue left x(0) in xsb, x(1) in fl_b, x(2) in fl_a: iteration i commits x(i+2)
+        // i = -1 commits x(1) = fl_b, i = 0 commits x(2) = fl_a, ...
+        for (int i = -1; i < T; i += 2) {
+            iteration(i, fl_b);
+            if (i + 1 < T) iteration(i + 1, fl_a);
+        }
+    } else {
     // fl_b holds x(t+1) on even frames, fl_a on odd ones
     for (int t = 0; t < T; t += 2) {
         frame(t, fl_b, fl_a);
         if (t + 1 < T) frame(t + 1, fl_a, fl_b);
+    }
     }
 
     if (bvalid) {
