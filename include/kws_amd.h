@@ -149,17 +149,18 @@ int kws_frontend_run(kws_frontend_handle h, const float* pcm, int B, int n_sampl
 int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host);
 
 /* Device-side decode window of the streaming loop (detector.py:122,168-209; utils/queue.py): per stream a
- * bounded FIFO of up to `max_chunks` softmax chunks (each <= max_frames frames).  kws_window_step, per stream:
+ * bounded FIFO of up to `max_chunks` softmax chunks (each <= max_frames frames).  ctc_decode2's per-frame rule
+ * (argmax over classes 1..C-2, strictly above `thres`) is a function of the frame alone, so the window stores each
+ * frame's word rather than its softmax row; `thres` is therefore fixed per handle.  kws_window_step, per stream:
  *   clear_before[b] != 0 -> empty the window first (silence: detector.py:171-177);
- *   append softmax[b] (dropping the oldest chunk when full); ctc_decode2(thres) over the concatenated window;
+ *   append softmax[b] (dropping the oldest chunk when full); ctc_decode2 over the concatenated window;
  *   hit[b] = label occurs in the decoded words (ctc_predict); on a hit the window is emptied and restart[b]=1
  *   (the caller passes it as the next kws_step reset_mask: detector.py:202-208). */
 typedef struct kws_window* kws_window_handle;
-int kws_window_create(int B, int max_chunks, int max_frames, int C, kws_window_handle* out);
+int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres, kws_window_handle* out);
 int kws_window_destroy(kws_window_handle h);
 int kws_window_step(kws_window_handle h, const float* softmax /*[B,T,C]*/, int T, const uint8_t* clear_before,
-                    const char* label, float thres, int32_t* hit /*[B]*/, uint8_t* restart /*[B] or NULL*/,
-                    void* stream);
+                    const char* label, int32_t* hit /*[B]*/, uint8_t* restart /*[B] or NULL*/, void* stream);
 
 /* OctbitMatMul: out[A,N] = (sum_k u8(x)[a,k] * Wq[n,k] - signed*bias[n]) * scale_w * s_x.
  *   x [A,K] f32, Wq [N,K] s8 (pre-transposed), bias [N] f32, out [A,N] f32.  K % 64 == 0, scale_w > 0.

@@ -63,9 +63,9 @@ _SIGNATURES = {
     "kws_frontend_frames": (_i, [ctypes.POINTER(KwsFrontendConfig), _i]),
     "kws_frontend_run": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "kws_frontend_mel_basis": (_i, [_vp, _vp]),
-    "kws_window_create": (_i, [_i, _i, _i, _i, ctypes.POINTER(_vp)]),
+    "kws_window_create": (_i, [_i, _i, _i, _i, _f, ctypes.POINTER(_vp)]),
     "kws_window_destroy": (_i, [_vp]),
-    "kws_window_step": (_i, [_vp, _vp, _i, _vp, ctypes.c_char_p, _f, _vp, _vp, _vp]),
+    "kws_window_step": (_i, [_vp, _vp, _i, _vp, ctypes.c_char_p, _vp, _vp, _vp]),
     "kws_octbit_matmul": (_i, [_vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
     "kws_octbit_quantize": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
 }

@@ -66,8 +66,9 @@ struct kws_model {
 };
 
 struct kws_window {
-    int B = 0, nq = 0, tmax = 0, C = 0;
-    float* ring = nullptr;
+    int B = 0, nq = 0, tmax = 0, tmax_pad = 0, C = 0;
+    float thres = 0.f;
+    int8_t* words = nullptr;
     int *lens = nullptr, *head = nullptr, *count = nullptr;
 };
 
@@ -512,7 +513,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     return KWS_OK;
 }
 
-int kws_window_create(int B, int max_chunks, int max_frames, int C, kws_window_handle* out) {
+int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres, kws_window_handle* out) {
     if (!out) return fail(KWS_ERR_INVALID_ARGUMENT, "out handle pointer is null");
     *out = nullptr;
     if (B < 1 || max_chunks < 1 || max_frames < 1 || C < 3 || C > 64)
@@ -521,8 +522,9 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, kws_window_h
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(KWS_ERR_NO_DEVICE, "no HIP device visible");
     kws_window* wnd = new (std::nothrow) kws_window();
     if (!wnd) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
-    wnd->B = B; wnd->nq = max_chunks; wnd->tmax = max_frames; wnd->C = C;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&wnd->ring), (size_t)B * max_chunks * max_frames * C * sizeof(float));
+    wnd->B = B; wnd->nq = max_chunks; wnd->tmax = max_frames; wnd->tmax_pad = (max_frames + 15) & ~15; wnd->C = C;
+    wnd->thres = thres;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&wnd->words), (size_t)B * max_chunks * wnd->tmax_pad);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->lens), (size_t)B * max_chunks * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->head), (size_t)B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->count), (size_t)B * sizeof(int));
@@ -536,7 +538,7 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, kws_window_h
 int kws_window_destroy(kws_window_handle h) {
     if (!h) return KWS_OK;
     hipDeviceSynchronize();
-    if (h->ring) hipFree(h->ring);
+    if (h->words) hipFree(h->words);
     if (h->lens) hipFree(h->lens);
     if (h->head) hipFree(h->head);
     if (h->count) hipFree(h->count);
@@ -545,7 +547,7 @@ int kws_window_destroy(kws_window_handle h) {
 }
 
 int kws_window_step(kws_window_handle h, const float* softmax, int T, const uint8_t* clear_before, const char* label,
-                    float thres, int32_t* hit, uint8_t* restart, void* stream) {
+                    int32_t* hit, uint8_t* restart, void* stream) {
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
     if (T < 0 || T > h->tmax) return fail(KWS_ERR_INVALID_ARGUMENT, "T=%d outside [0,%d]", T, h->tmax);
     if (!hit || (!softmax && T > 0) || !label) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
@@ -558,9 +560,9 @@ int kws_window_step(kws_window_handle h, const float* softmax, int T, const uint
         p.label[i] = label[i] - '0';
     }
     p.label_len = n;
-    p.ring = h->ring; p.lens = h->lens; p.head = h->head; p.count = h->count;
+    p.words = h->words; p.lens = h->lens; p.head = h->head; p.count = h->count;
     p.softmax = softmax; p.clear_before = clear_before; p.hit = hit; p.restart = restart;
-    p.thres = thres; p.B = h->B; p.T = T; p.C = h->C; p.nq = h->nq; p.tmax = h->tmax;
+    p.thres = h->thres; p.B = h->B; p.T = T; p.C = h->C; p.nq = h->nq; p.tmax = h->tmax_pad;
     hipError_t e = kws::launch_window_step(p, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "launch window_step");
     return KWS_OK;

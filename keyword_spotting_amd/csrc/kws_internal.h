@@ -63,7 +63,7 @@ hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStr
 
 // decode window of the stream manager (stream_kernels.hip)
 struct WindowParams {
-    float* ring;              // [B][nq][tmax][C]
+    int8_t* words;            // [B][nq][tmax] per-frame ctc_decode2 word (-1 none); tmax % 16 == 0
     int* lens;                // [B][nq]
     int* head;                // [B]
     int* count;               // [B]

@@ -160,7 +160,7 @@ class StreamManager(object):
         self._win = ctypes.c_void_p()
         with torch.cuda.device(model.device):
             _lib.check(self._lib.kws_window_create(self.batch, int(window_chunks), int(max_frames),
-                                                   self.config.num_classes, ctypes.byref(self._win)))
+                                                   self.config.num_classes, float(decode_thres), ctypes.byref(self._win)))
         dev = model.device
         self.state = model.zero_state(self.batch)
         self.restart = torch.zeros(self.batch, dtype=torch.uint8, device=dev)     # reset requested by a trigger
@@ -198,8 +198,7 @@ class StreamManager(object):
         sm = r["softmax"]
         with torch.cuda.device(dev):
             _lib.check(self._lib.kws_window_step(self._win, _lib.ptr(sm), int(sm.shape[1]), _lib.ptr(silent), self.label,
-                                                 float(self.decode_thres), _lib.ptr(self.hit), _lib.ptr(self.restart),
-                                                 _lib.current_stream_ptr()))
+                                                 _lib.ptr(self.hit), _lib.ptr(self.restart), _lib.current_stream_ptr()))
         return self.hit
 
     def feed_pcm(self, pcm_chunk, frontend):
