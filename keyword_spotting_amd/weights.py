@@ -93,3 +93,57 @@ def load_npz(path):
     n = 1 + max(int(k[1:].split("_")[0]) for k in z.files if k.startswith("l"))
     return dict(layers=[{k: z["l%d_%s" % (l, k)] for k in ("Wg", "bg", "Wc", "bc")} for l in range(n)],
                 Wfc=z["Wfc"], bfc=z["bfc"])
+
+
+def from_tf_variables(config, variables):
+    """Canonical dict from a {TF variable name: array} mapping (e.g. a checkpoint dumped to .npz).
+
+    Names as the reference graph creates them (models/rnn_ctc.py:236-243 scope "drnn", :265-273):
+      [model/]drnn/multi_rnn_cell/cell_<l>/gru_cell/{gates,candidate}/{kernel,bias}     TF >= 1.2
+      ...                                            {gates,candidate}/{weights,biases}  TF 1.0-1.1
+      [model/]weightsClasses, [model/]biasesClasses
+    Optimiser slots (".../Adam", ".../Adam_1") and a trailing ":0" are ignored."""
+    import re
+    pat = re.compile(r"(?:^|/)cell_(\d+)/gru_cell/(gates|candidate)/(kernel|weights|bias|biases)(?::0)?$")
+    slot = {("gates", "kernel"): "Wg", ("gates", "weights"): "Wg", ("gates", "bias"): "bg", ("gates", "biases"): "bg",
+            ("candidate", "kernel"): "Wc", ("candidate", "weights"): "Wc", ("candidate", "bias"): "bc",
+            ("candidate", "biases"): "bc"}
+    layers = [dict() for _ in range(config.num_layers)]
+    w = dict(layers=layers)
+    for name, arr in variables.items():
+        m = pat.search(name)
+        if m:
+            l = int(m.group(1))
+            if l >= config.num_layers:
+                raise ValueError("variable %s belongs to layer %d, config has %d layers" % (name, l, config.num_layers))
+            key = slot[(m.group(2), m.group(3))]
+            if key in layers[l]:
+                raise ValueError("two variables map to layer %d %s (second: %s)" % (l, key, name))
+            layers[l][key] = np.asarray(arr, np.float32)
+            continue
+        base = name[:-2] if name.endswith(":0") else name
+        base = base.rsplit("/", 1)[-1]
+        if base == "weightsClasses":
+            w["Wfc"] = np.asarray(arr, np.float32)
+        elif base == "biasesClasses":
+            w["bfc"] = np.asarray(arr, np.float32)
+    for l, lay in enumerate(layers):
+        missing = [k for k in ("Wg", "bg", "Wc", "bc") if k not in lay]
+        if missing:
+            raise ValueError("layer %d: no variable found for %s" % (l, ", ".join(missing)))
+    for k in ("Wfc", "bfc"):
+        if k not in w:
+            raise ValueError("no variable found for %s (weightsClasses / biasesClasses)" % k)
+    check_shapes(config, w)
+    return w
+
+
+def to_tf_variables(w, new_names=True, prefix="model/"):
+    """Inverse of from_tf_variables (for round-trip tests and for exporting back)."""
+    kn, bn = ("kernel", "bias") if new_names else ("weights", "biases")
+    out = {prefix + "weightsClasses": w["Wfc"], prefix + "biasesClasses": w["bfc"]}
+    for l, lay in enumerate(w["layers"]):
+        base = "%sdrnn/multi_rnn_cell/cell_%d/gru_cell/" % (prefix, l)
+        out[base + "gates/" + kn], out[base + "gates/" + bn] = lay["Wg"], lay["bg"]
+        out[base + "candidate/" + kn], out[base + "candidate/" + bn] = lay["Wc"], lay["bc"]
+    return out

@@ -1,4 +1,5 @@
 """Host-side logic that needs no GPU: weight containers, config, window queue, sharding."""
+import os
 import numpy as np
 import pytest
 
@@ -79,3 +80,27 @@ def test_chunk_framer_matches_reference_arithmetic():
     for sizes in ([3600] * 20, [1234, 4000, 800, 160, 159, 4001], [400], [399, 1]):
         fr = ChunkFramer()
         assert [fr.push(n) for n in sizes] == D.chunk_frame_counts(sizes)
+
+
+def test_tf_variable_names_round_trip(tmp_path):
+    """weights.from_tf_variables accepts both TF naming generations and ignores optimiser slots."""
+    import subprocess, sys
+    from keyword_spotting_amd import get_config, weights
+    cfg = get_config()
+    w = weights.init_weights(cfg, seed=3)
+    for new in (True, False):
+        v = weights.to_tf_variables(w, new_names=new)
+        v = {k + ":0": a for k, a in v.items()}
+        v["model/drnn/multi_rnn_cell/cell_0/gru_cell/gates/kernel/Adam:0"] = np.zeros((168, 256), np.float32)
+        back = weights.from_tf_variables(cfg, v)
+        np.testing.assert_array_equal(weights.to_blob(cfg, back), weights.to_blob(cfg, w))
+    bad = weights.to_tf_variables(w)
+    del bad["model/drnn/multi_rnn_cell/cell_1/gru_cell/candidate/bias"]
+    with pytest.raises(ValueError, match="layer 1"):
+        weights.from_tf_variables(cfg, bad)
+    src = tmp_path / "vars.npz"
+    np.savez(src, **weights.to_tf_variables(w))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "convert_weights.py"), str(src), "--out",
+                           str(tmp_path / "m")])
+    np.testing.assert_array_equal(np.fromfile(tmp_path / "m.blob", np.float32), weights.to_blob(cfg, w))
