@@ -17,9 +17,8 @@ ap.add_argument("--out", required=True)
 ap.add_argument("--n-mel", type=int, default=40)
 ap.add_argument("--hidden", type=int, default=128)
 ap.add_argument("--layers", type=int, default=2)
-ap.add_argument("--classes", type=int, default=6)
 a = ap.parse_args()
-cfg = get_config(n_mel=a.n_mel, hidden_size=a.hidden, num_layers=a.layers, num_classes=a.classes)
+cfg = get_config(n_mel=a.n_mel, hidden_size=a.hidden, num_layers=a.layers)
 z = np.load(a.src)
 if any("gru_cell" in k for k in z.files):
     w = weights.from_tf_variables(cfg, {k: z[k] for k in z.files})
