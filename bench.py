@@ -127,8 +127,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="streams per GPU")
     ap.add_argument("--frames", type=int, default=300, help="mel frames per stream per step")
     ap.add_argument("--kernel", default="auto")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = the reference arithmetic (headline); bf16 = BASELINE configs[2] variant (secondary)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "int8"],
+                    help="fp32 = the reference arithmetic (headline); bf16 / int8 = BASELINE configs[2] variants (secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the "
                     "multi-process path on a box with fewer GPUs than ranks")
@@ -208,6 +208,10 @@ def main():
         dom_flops = FLOP_PER_FRAME["total"] if args.precision == "bf16" else FLOP_PER_FRAME["layer"][dom]
         achieved = dom_flops * B * T / (dom_ms * 1e-3) / 1e12
         peak = 2500.0 if args.precision == "bf16" else PEAK_FP32_TFLOPS
+        if args.precision == "int8" and dom >= 1:
+            # exact emulation of the reference's int16-saturating pair sums runs on the packed-int16 VALU
+            # (3 instructions per 2 pairs = 8 int ops / 3 lane-instructions); MFMA i8 cannot saturate
+            peak = 256 * 64 * 2.4e9 * (8.0 / 3.0) / 1e12
         all_ms = sum(k[0] / max(k[1], 1) for k in ktimes)
         dom_name = "gru_layer_resident<%s>" % ("10, true, false" if dom == 0 else "32, false, true")
         traffic, traffic_src = (pmc_traffic(dom_name) if model.kernel != "generic" and args.precision == "fp32"
@@ -216,17 +220,19 @@ def main():
             "metric": "mel-frames/s (real-time 10 ms-hop audio streams sustained = value/100)",
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 (secondary line; headline is f32)",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 (secondary line; headline is f32)",
+                                           "int8": "u8 x s8 -> sat i16 -> i32, layer 0 f32 (secondary line; headline is f32)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[1]: 2xGRU h=128 n_mel=40 6-class, %d concurrent streams/GPU x %d frames "
                                    "per step, fp32, state carried on device, logits+softmax+fused ctc_decode2" % (B, T),
                        "streams_per_gpu": B, "frames_per_step": T, "parallelism": "utterance-dp%d" % world,
                        "kernel": model.kernel},
             "realtime_streams": value / 100.0,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu-pk-i16 (secondary line)" if args.precision == "int8" and dom >= 1 else "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": (209 if args.precision == "bf16" else (512 + 49 if dom else 160 + 512)) * B * T,
                          "kernel": ("gru_stack_bf16 (both layers fused)" if args.precision == "bf16" else
+                                    "gru_layer_octbit layer %d + projection" % dom if args.precision == "int8" and dom >= 1 else
                                     "gru_layer_%s layer %d" % ("resident" if model.kernel != "generic" else "generic", dom)),
                          "kernel_ms": dom_ms, "launches": ktimes[dom][1],
                          "all_layers_tflops": FLOP_PER_FRAME["total"] * B * T / (all_ms * 1e-3) / 1e12,

@@ -57,10 +57,15 @@ typedef struct kws_config {
     int32_t num_classes; /* C : 3..8 (space, words..., blank)                               */
     int32_t use_relu;    /* models/rnn_ctc.py:280                                           */
     float value_clip;    /* models/rnn_ctc.py:282 : >0 and use_relu -> clip logits to [0,20] */
-    int32_t precision;   /* KWS_FP32 (reference arithmetic) or KWS_BF16 (BASELINE configs[2]: bf16 weights and
-                            matmul inputs, fp32 accumulate / state / activations; H=128, L<=2, n_mel%4==0, <=64) */
+    int32_t precision;   /* KWS_FP32 (reference arithmetic); KWS_BF16 (BASELINE configs[2]: bf16 weights and
+                            matmul inputs, fp32 accumulate / state / activations; H=128, L<=2, n_mel%4==0, <=64);
+                            KWS_INT8 (BASELINE configs[2], the graph octbit/octbit_graph.py:461-485 produces: the
+                            gate/candidate MatMuls of cell_1.. and the class projection are OctbitMatMul calls --
+                            name rule :218-225, weights quantised at kws_create by :191-215, op arithmetic
+                            octbit_mat_mul_op.cc:90-181 incl. the int16 pair saturation, activation range per
+                            stream as the batch-1 graph has it; layer 0, biases, activations fp32; H=128) */
 } kws_config;
-enum { KWS_FP32 = 0, KWS_BF16 = 1 };
+enum { KWS_FP32 = 0, KWS_BF16 = 1, KWS_INT8 = 2 };
 
 typedef struct kws_model* kws_handle;
 

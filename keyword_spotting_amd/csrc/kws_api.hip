@@ -53,6 +53,15 @@ struct kws_model {
     // bf16 stack: offsets (floats) of the packed bf16 A operands
     size_t bf_w[2] = {0, 0}, bf_wfc = 0;
     int bf_kx0 = 0;
+    // int8 ("octbit") variant: per quantised layer the packed int16 couples + 127*colsum, and the projection
+    struct OctLayer { bool quantised = false; size_t wg = 0, wc = 0, b127 = 0; float scale_g = 0.f, scale_c = 0.f; };
+    std::vector<OctLayer> oct;
+    size_t oct_wfc = 0, oct_b127fc = 0;
+    float oct_scale_fc = 0.f;
+    uint32_t* oct_aq = nullptr;      // activation exchange [groups][2][16][128]
+    float2* oct_range = nullptr;     // [groups*16]
+    int32_t* oct_prev = nullptr;     // [B] copy of prev_word
+    size_t oct_groups = 0;
     float* d_weights = nullptr;
     float4* scratch[2] = {nullptr, nullptr};
     size_t scratch_bytes = 0;
@@ -118,7 +127,11 @@ bool config_ok(const kws_config* c, int* code) {
     if (c->num_layers < 1 || c->num_layers > 8) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "num_layers=%d out of range [1,8]", c->num_layers); return false; }
     if (c->num_classes < 3 || c->num_classes > kws::kMaxClasses) { *code = fail(KWS_ERR_UNSUPPORTED, "num_classes=%d unsupported (3..8)", c->num_classes); return false; }
     if (c->hidden != 64 && c->hidden != 128 && c->hidden != 256) { *code = fail(KWS_ERR_UNSUPPORTED, "hidden=%d unsupported (64, 128, 256)", c->hidden); return false; }
-    if (c->precision != KWS_FP32 && c->precision != KWS_BF16) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "unknown precision %d", c->precision); return false; }
+    if (c->precision == KWS_INT8 && c->hidden != 128) {
+        *code = fail(KWS_ERR_UNSUPPORTED, "int8 path needs hidden=128 (OctbitMatMul K=2*hidden must be a multiple of 64 and the kernel is built for 128); got %d", c->hidden);
+        return false;
+    }
+    if (c->precision != KWS_FP32 && c->precision != KWS_BF16 && c->precision != KWS_INT8) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "unknown precision %d", c->precision); return false; }
     if (c->precision == KWS_BF16 && !kws::gru_bf16_supported(c->hidden, c->n_mel, c->num_layers)) {
         *code = fail(KWS_ERR_UNSUPPORTED, "bf16 path needs hidden=128, num_layers<=2, n_mel%%4==0 and <=64; got hidden=%d layers=%d n_mel=%d",
                      c->hidden, c->num_layers, c->n_mel);
@@ -294,6 +307,73 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
                 }
     }
 
+    if (cfg->precision == KWS_INT8) {
+        // octbit/octbit_graph.py:218-225: every MatMul outside cell_0 is quantised -> layers >= 1 and the projection
+        auto pack16 = [](int8_t lo, int8_t hi) { return (uint32_t)(uint16_t)(int16_t)lo | ((uint32_t)(uint16_t)(int16_t)hi << 16); };
+        const float* q = static_cast<const float*>(weights_blob);
+        int in_l = cfg->n_mel;
+        m->oct.resize(cfg->num_layers);
+        for (int l = 0; l < cfg->num_layers; ++l) {
+            const int K = in_l + H;
+            const float* Wg = q;
+            const float* Wc = Wg + (size_t)K * 2 * H + 2 * H;
+            if (l >= 1) {
+                kws_model::OctLayer& O = m->oct[l];
+                O.quantised = true;
+                std::vector<int8_t> gq((size_t)2 * H * K), cq((size_t)H * K);
+                std::vector<float> gb(2 * H), cb(H);
+                int rc = kws_octbit_quantize(Wg, K, 2 * H, gq.data(), &O.scale_g, gb.data());
+                if (rc == KWS_OK) rc = kws_octbit_quantize(Wc, K, H, cq.data(), &O.scale_c, cb.data());
+                if (rc != KWS_OK) { delete m; return rc; }
+                O.b127 = reserve(3 * (size_t)H);
+                for (int j = 0; j < 2 * H; ++j) host[O.b127 + j] = gb[j];
+                for (int j = 0; j < H; ++j) host[O.b127 + 2 * H + j] = cb[j];
+                O.wg = reserve((size_t)2 * 4 * 64 * 64);
+                {
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(&host[O.wg]);
+                    for (int kh = 0; kh < 2; ++kh)
+                        for (int ug = 0; ug < 4; ++ug)
+                            for (int c2 = 0; c2 < 64; ++c2)
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int n = 64 * ug + lane, k0 = 128 * kh + 4 * (c2 / 2) + (c2 & 1);
+                                    dst[((size_t)(kh * 4 + ug) * 64 + c2) * 64 + lane] =
+                                        pack16(gq[(size_t)n * K + k0], gq[(size_t)n * K + k0 + 2]);
+                                }
+                }
+                O.wc = reserve((size_t)4 * 2 * 32 * 64);
+                {
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(&host[O.wc]);
+                    for (int kq = 0; kq < 4; ++kq)
+                        for (int uc = 0; uc < 2; ++uc)
+                            for (int c2 = 0; c2 < 32; ++c2)
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int n = 64 * uc + lane, k0 = 64 * kq + 4 * (c2 / 2) + (c2 & 1);
+                                    dst[((size_t)(kq * 2 + uc) * 32 + c2) * 64 + lane] =
+                                        pack16(cq[(size_t)n * K + k0], cq[(size_t)n * K + k0 + 2]);
+                                }
+                }
+            }
+            q = Wc + (size_t)K * H + H;
+            in_l = H;
+        }
+        std::vector<int8_t> fq((size_t)C * H);
+        std::vector<float> fb(C);
+        int rc = kws_octbit_quantize(Wfc, H, C, fq.data(), &m->oct_scale_fc, fb.data());
+        if (rc != KWS_OK) { delete m; return rc; }
+        m->oct_b127fc = reserve(kws::kMaxClasses);
+        for (int c = 0; c < C; ++c) host[m->oct_b127fc + c] = fb[c];
+        m->oct_wfc = reserve((size_t)8 * 4 * 2 * kws::kMaxClasses);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&host[m->oct_wfc]);
+        for (int n = 0; n < 8; ++n)
+            for (int g = 0; g < 4; ++g)
+                for (int c = 0; c < kws::kMaxClasses; ++c)
+                    for (int e = 0; e < 2; ++e) {
+                        const int k0 = 16 * n + 4 * g + e;
+                        dst[((size_t)(n * 4 + g) * kws::kMaxClasses + c) * 2 + e] =
+                            c < C ? pack16(fq[(size_t)c * H + k0], fq[(size_t)c * H + k0 + 2]) : 0u;
+                    }
+    }
+
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_weights), host.size() * sizeof(float));
     if (e != hipSuccess) { delete m; return hip_fail(e, "hipMalloc(weights)"); }
     e = hipMemcpy(m->d_weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -316,6 +396,9 @@ int kws_destroy(kws_handle h) {
     for (auto ev : h->event_pool) hipEventDestroy(ev);
     if (h->d_weights) hipFree(h->d_weights);
     for (int i = 0; i < 2; ++i) if (h->scratch[i]) hipFree(h->scratch[i]);
+    if (h->oct_aq) hipFree(h->oct_aq);
+    if (h->oct_range) hipFree(h->oct_range);
+    if (h->oct_prev) hipFree(h->oct_prev);
     delete h;
     return KWS_OK;
 }
@@ -334,14 +417,25 @@ int kws_set_kernel(kws_handle h, int kind) {
 }
 
 static int ensure_scratch(kws_handle h, int B, int T) {
-    if (h->cfg.num_layers < 2) return KWS_OK;
     const size_t groups = (size_t)(B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
+    if (h->cfg.precision == KWS_INT8 && groups > h->oct_groups) {
+        KWS_HIP(hipDeviceSynchronize());
+        if (h->oct_aq) hipFree(h->oct_aq);
+        if (h->oct_range) hipFree(h->oct_range);
+        if (h->oct_prev) hipFree(h->oct_prev);
+        h->oct_aq = nullptr; h->oct_range = nullptr; h->oct_prev = nullptr; h->oct_groups = 0;
+        KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->oct_aq), groups * 2 * 16 * 128 * sizeof(uint32_t)));
+        KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->oct_range), groups * 16 * sizeof(float2)));
+        KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->oct_prev), groups * 16 * sizeof(int32_t)));
+        h->oct_groups = groups;
+    }
+    if (h->cfg.num_layers < 2 && h->cfg.precision != KWS_INT8) return KWS_OK;
     const size_t bytes = groups * (size_t)T * h->cfg.hidden * 16 * sizeof(float);
     if (bytes <= h->scratch_bytes) return KWS_OK;
     KWS_HIP(hipDeviceSynchronize());
     for (int i = 0; i < 2; ++i) if (h->scratch[i]) { hipFree(h->scratch[i]); h->scratch[i] = nullptr; }
     h->scratch_bytes = 0;
-    const int nbuf = h->cfg.num_layers > 2 ? 2 : 1;
+    const int nbuf = (h->cfg.num_layers > 2 || h->cfg.precision == KWS_INT8) ? 2 : 1;
     for (int i = 0; i < nbuf; ++i) KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
     h->scratch_bytes = bytes;
     return KWS_OK;
@@ -435,9 +529,14 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     int rc = ensure_scratch(h, B, T);
     if (rc != KWS_OK) return rc;
 
+    const bool int8 = c.precision == KWS_INT8;
+    if (int8 && prev_word)
+        KWS_HIP(hipMemcpyAsync(h->oct_prev, prev_word, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     for (int l = 0; l < L; ++l) {
         const LayerDev& Ld = h->layers[l];
-        const bool first = l == 0, last = l == L - 1;
+        // int8: every GRU layer hands its output rows to the next stage through the xl scratch; the class
+        // projection is its own OctbitMatMul call over the whole [T,H] block (launch_octbit_fc below)
+        const bool first = l == 0, last = !int8 && l == L - 1;
         const bool resident = h->kernel_kind == KWS_KERNEL_RESIDENT ||
                               (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok);
         kws::GruLayerParams p;
@@ -480,9 +579,42 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             }
             KWS_HIP(hipEventRecord(ea, st));
         }
-        hipError_t e = resident ? kws::launch_gru_layer_resident(p, first, last, st)
-                                : kws::launch_gru_layer_generic(p, H, first, last, st);
-        if (e != hipSuccess) return hip_fail(e, resident ? "launch gru_layer_resident" : "launch gru_layer_generic");
+        hipError_t e;
+        if (int8 && h->oct[l].quantised) {
+            const kws_model::OctLayer& O = h->oct[l];
+            kws::GruOctbitParams op;
+            memset(&op, 0, sizeof(op));
+            op.wg = reinterpret_cast<const uint32_t*>(h->d_weights + O.wg);
+            op.wc = reinterpret_cast<const uint32_t*>(h->d_weights + O.wc);
+            op.bias = p.bias; op.b127 = h->d_weights + O.b127;
+            op.scale_g = O.scale_g; op.scale_c = O.scale_c;
+            op.x_prev = p.x_prev; op.h_out = p.h_out;
+            op.state_in = p.state_in; op.state_out = p.state_out;
+            op.seq_len = seq_len; op.reset = reset_mask;
+            op.aq = h->oct_aq; op.B = B; op.T = T;
+            e = kws::launch_gru_layer_octbit(op, st);
+            if (e != hipSuccess) return hip_fail(e, "launch gru_layer_octbit");
+        } else {
+            e = resident ? kws::launch_gru_layer_resident(p, first, last, st)
+                         : kws::launch_gru_layer_generic(p, H, first, last, st);
+            if (e != hipSuccess) return hip_fail(e, resident ? "launch gru_layer_resident" : "launch gru_layer_generic");
+        }
+        if (int8 && l == L - 1) {
+            kws::OctbitFcParams fp;
+            memset(&fp, 0, sizeof(fp));
+            fp.wfc = reinterpret_cast<const uint32_t*>(h->d_weights + h->oct_wfc);
+            fp.b127 = h->d_weights + h->oct_b127fc;
+            fp.bfc = h->d_weights + h->bfc_off;
+            fp.scale_w = h->oct_scale_fc;
+            fp.h_top = h->scratch[l & 1];
+            fp.range = h->oct_range;
+            fp.prev_in = prev_word ? h->oct_prev : nullptr;
+            fp.logits = logits; fp.softmax = softmax; fp.tokens = tokens; fp.prev_word = prev_word;
+            fp.decode_thres = decode2_thres; fp.value_clip = c.value_clip; fp.use_relu = c.use_relu;
+            fp.B = B; fp.T = T; fp.C = c.num_classes;
+            e = kws::launch_octbit_fc(fp, st);
+            if (e != hipSuccess) return hip_fail(e, "launch octbit_fc");
+        }
         if (h->profiling) {
             KWS_HIP(hipEventRecord(eb, st));
             h->pending.push_back({l, ea, eb});

@@ -61,6 +61,37 @@ struct GruBf16Params {
 bool gru_bf16_supported(int hidden, int n_mel, int layers);
 hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st);
 
+// int8 ("octbit") GRU layers and class projection (gru_octbit.hip)
+struct GruOctbitParams {
+    const uint32_t* wg;     // gates  [2 K-halves][4 unit groups][64 = 32 couples x (even,odd)][64 lanes]  int16 pairs
+    const uint32_t* wc;     // cand.  [4 K-quarters][2 unit groups][32][64 lanes]
+    const float* bias;      // [3][128] (r, u, c)
+    const float* b127;      // [384]  127 * column sums of Wq: gates 256, candidate 128 (octbit_graph.py:202-204)
+    float scale_g, scale_c; // octize_weight_int8_signed scales
+    const float4* x_prev;   // previous layer's output, xl layout
+    float4* h_out;          // this layer's output, xl layout
+    const float* state_in;  // [B,128]
+    float* state_out;
+    const int32_t* seq_len;
+    const uint8_t* reset;
+    uint32_t* aq;           // activation exchange [G][2][16 streams][128 dwords]
+    int B, T;
+};
+struct OctbitFcParams {
+    const uint32_t* wfc;    // [8 tiles][4 g][kMaxClasses][even,odd] int16 pairs
+    const float* b127;      // [kMaxClasses]
+    const float* bfc;       // [16] padded
+    float scale_w;
+    const float4* h_top;    // top layer output, xl layout
+    float2* range;          // [G*16] (min, max) of each stream's [T,H] block
+    const int32_t* prev_in; // copy of prev_word taken before the launch (or null)
+    float* logits; float* softmax; int8_t* tokens; int32_t* prev_word;
+    float decode_thres, value_clip;
+    int use_relu, B, T, C;
+};
+hipError_t launch_gru_layer_octbit(const GruOctbitParams& p, hipStream_t st);
+hipError_t launch_octbit_fc(const OctbitFcParams& p, hipStream_t st);
+
 // decode window of the stream manager (stream_kernels.hip)
 struct WindowParams {
     int8_t* words;            // [B][nq][tmax] per-frame ctc_decode2 word (-1 none); tmax % 16 == 0

@@ -221,3 +221,66 @@ def gru_forward_bf16(w, mel, state=None, seq_len=None):
                 top[:, t, :] = np.where(live, hn, 0.0)
     logits = bf16_round(top.reshape(-1, hdim).astype(np.float32)).astype(np.float64) @ wfc + w["bfc"].astype(np.float64)
     return logits.reshape(b, t_len, -1), np.stack(h)
+
+
+# --------------------------------------------------------------------------------------
+# int8 ("octbit") variant -- the graph octbit/octbit_graph.py produces from the deploy model:
+# every MatMul whose node name passes default_octbit_matmul_name_check (:218-225) becomes an
+# OctbitMatMul (octbit_mat_mul_op.cc) on weights quantised by octize_weight_int8_signed (:191-215).
+# For the GRU that is the gates and candidate matmuls of cell_1.. (cell_0 is excluded by name) and
+# the class projection `model/MatMul`; bias adds, sigmoid/tanh, the state update and the whole of
+# layer 0 stay fp32.  The graph runs batch 1, so each GRU matmul is one op call on a [1, I+H] row
+# (activation range = that row's min/max) and the projection is one call on the call's [T, H] block
+# (one range over all T frames, zero rows of finished frames included).
+# The op arithmetic is PINNED (octbit_ops_test.py known answers); the GRU wiring around it is
+# PARITY UNPINNED like the rest of this file.
+# --------------------------------------------------------------------------------------
+def octbit_layer_is_quantised(layer):
+    from oracle import octbit_oracle as Q
+    return Q.default_octbit_matmul_name_check(
+        "model/drnn/multi_rnn_cell/cell_%d/gru_cell/gates/MatMul" % layer)
+
+
+def gru_forward_octbit(w, mel, state=None, seq_len=None):
+    from oracle import octbit_oracle as Q
+    f32 = np.float32
+    mel = np.asarray(mel, f32)
+    b, t_len, _ = mel.shape
+    nl = len(w["layers"])
+    hdim = w["Wfc"].shape[0]
+    if state is None:
+        state = np.zeros((nl, b, hdim), f32)
+    h = [np.array(state[l], f32) for l in range(nl)]
+    if seq_len is None:
+        seq_len = np.full(b, t_len, np.int64)
+    seq_len = np.asarray(seq_len)
+    qw = []
+    for l, lay in enumerate(w["layers"]):
+        qw.append(dict(g=Q.octize_weight_int8_signed(lay["Wg"]), c=Q.octize_weight_int8_signed(lay["Wc"]))
+                  if octbit_layer_is_quantised(l) else None)
+    top = np.zeros((b, t_len, hdim), f32)
+    for t in range(t_len):
+        live = (t < seq_len)[:, None]
+        x = mel[:, t, :]
+        for l in range(nl):
+            lay = w["layers"][l]
+            if qw[l] is None:
+                hn = gru_cell(x, h[l], lay, f32)
+            else:
+                (gq, gs, gb), (cq, cs, cb) = qw[l]["g"], qw[l]["c"]
+                g = _sigmoid((Q.octbit_rows(np.concatenate([x, h[l]], 1), gq, gs, gb) + lay["bg"].astype(f32)).astype(f32))
+                r, u = g[:, :hdim], g[:, hdim:]
+                c = np.tanh((Q.octbit_rows(np.concatenate([x, (r * h[l]).astype(f32)], 1), cq, cs, cb)
+                             + lay["bc"].astype(f32)).astype(f32))
+                hn = (u * h[l] + (f32(1.0) - u) * c).astype(f32)
+            h[l] = np.where(live, hn, h[l])
+            x = hn
+        top[:, t, :] = np.where(live, hn, f32(0))
+    if Q.default_octbit_matmul_name_check("model/MatMul"):
+        fq, fs, fb = Q.octize_weight_int8_signed(w["Wfc"])
+        # pad the class rows are not needed: N is free, only K % 64 == 0 is required
+        flat = Q.octbit_rows(top.reshape(b * t_len, hdim), fq, fs, fb, groups=np.repeat(np.arange(b), t_len))
+    else:
+        flat = top.reshape(-1, hdim) @ w["Wfc"].astype(f32)
+    logits = (flat + w["bfc"].astype(f32)).astype(f32).reshape(b, t_len, -1)
+    return logits, np.stack(h).astype(f32)

@@ -60,3 +60,38 @@ def octbit_matmul_ref(x, wq, scale_w, bias):
                 o = np.float32(o - np.float32(bias[j]))
             out[a, j] = np.float32(o * scale)
     return out
+
+
+def octbit_rows(x, wq, scale_w, bias, groups=None):
+    """octbit/octbit_mat_mul_op.cc:90-181 vectorised over R independent calls.
+
+    x [R,K]; rows sharing a value in `groups` ([R] ints) form ONE op call (its `[A,K]` input: one
+    min/max over all of them, :92-99); groups=None makes every row its own call (the deployed graph runs
+    batch 1, so each GRU matmul sees A == 1).  The four i32 SSE lanes (:141-175) add up exactly in float
+    (|sum| < 2^24), so the lane fold is not modelled separately here -- octbit_matmul_ref keeps it.
+    An all-zero call has bscale == 0 and divides 0/0 in the reference; its output is defined here as 0
+    (what x86 yields: the NaN casts to q == 0, and the output scale is 0)."""
+    x = np.ascontiguousarray(x, np.float32)
+    r_rows, k = x.shape
+    n = wq.shape[0]
+    assert scale_w > 0 and k % 64 == 0
+    groups = np.arange(r_rows) if groups is None else np.asarray(groups)
+    uniq, inv = np.unique(groups, return_inverse=True)
+    mn = np.full(len(uniq), np.inf, np.float32)
+    mx = np.full(len(uniq), -np.inf, np.float32)
+    np.minimum.at(mn, inv, x.min(axis=1))
+    np.maximum.at(mx, inv, x.max(axis=1))
+    signed_g = mn < 0
+    bscale_g = np.where(signed_g, np.maximum(-mn, mx) / np.float32(127), mx / np.float32(254)).astype(np.float32)
+    signed, bscale = signed_g[inv], bscale_g[inv]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        quo = (x / bscale[:, None]).astype(np.float64)                  # float quotient, widened for round()
+    quo = np.where(bscale[:, None] == 0, 0.0, quo)
+    q = np.sign(quo) * np.floor(np.abs(quo) + 0.5) + np.where(signed, 127.0, 0.0)[:, None]
+    q = q.astype(np.int64).astype(np.uint8).astype(np.int32)
+    wt = np.ascontiguousarray(wq.T).astype(np.int32)                    # [K, N]
+    pair = q[:, 0::2, None] * wt[None, 0::2, :] + q[:, 1::2, None] * wt[None, 1::2, :]
+    acc = np.clip(pair, -32768, 32767).sum(axis=1)                      # [R, N] exact
+    o = acc.astype(np.float32) - np.where(signed[:, None], np.asarray(bias, np.float32)[None, :], np.float32(0))
+    scale = (np.float32(scale_w) * bscale).astype(np.float32)
+    return (o.astype(np.float32) * scale[:, None]).astype(np.float32)

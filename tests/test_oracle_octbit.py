@@ -83,3 +83,47 @@ def test_quantised_matmul_tracks_float(oracle_c):
     assert rc == 0
     ref = x @ w
     assert np.abs(got - ref).max() < 0.05 * np.abs(ref).max()
+
+
+def test_vectorised_rows_equal_the_op_per_call(oracle_c):
+    """octbit_rows (used by the int8 GRU oracle) == one op call per group of rows, C and numpy restatements."""
+    rng = np.random.default_rng(21)
+    k, n = 256, 40
+    wq = rng.integers(-127, 128, (n, k)).astype(np.int8)
+    bias = (127.0 * wq.astype(np.float64).sum(1)).astype(np.float32)
+    x = rng.standard_normal((6, k)).astype(np.float32)
+    x[2] = np.abs(x[2])                 # unsigned branch
+    x[3] = 0.0                          # all-zero call: defined as 0 output
+    x[4, ::2] = 3.0; x[4, 1::2] = 2.5   # heavy saturation
+    rows = O.octbit_rows(x, wq, 0.02, bias)
+    for i in (0, 1, 2, 4, 5):
+        rc, got = oracle_c.octbit_matmul(x[i:i + 1], wq, 0.02, bias)
+        assert rc == 0
+        np.testing.assert_array_equal(rows[i], got[0])
+    assert not rows[3].any()
+    grouped = O.octbit_rows(x[[0, 1, 5]], wq, 0.02, bias, groups=[7, 7, 7])
+    rc, got = oracle_c.octbit_matmul(np.ascontiguousarray(x[[0, 1, 5]]), wq, 0.02, bias)
+    np.testing.assert_array_equal(grouped, got)
+
+
+def test_int8_gru_oracle_structure():
+    from oracle import gru_oracle as G
+    assert not G.octbit_layer_is_quantised(0) and G.octbit_layer_is_quantised(1) and G.octbit_layer_is_quantised(3)
+    w = G.random_weights(40, 128, 2, 6, seed=5)
+    mel = G.synthetic_mel(3, 12, 40, seed=6)
+    lg, st = G.gru_forward_octbit(w, mel)
+    lf, sf = G.gru_forward(w, mel)
+    np.testing.assert_array_equal(st[0], sf[0])                   # cell_0 is not quantised (name rule)
+    assert 1e-4 < np.abs(st[1] - sf[1]).max() < 0.5               # cell_1 is
+    # state is chunking-invariant; the projection's range is per call, so logits are not
+    l1, s1 = G.gru_forward_octbit(w, mel[:, :5])
+    l2, s2 = G.gru_forward_octbit(w, mel[:, 5:], s1)
+    np.testing.assert_array_equal(s2, st)
+    assert not np.array_equal(np.concatenate([l1, l2], 1), lg)
+    # finished frames emit the zero row -> logits == bias; their state is frozen
+    seq = np.array([12, 4, 0])
+    lm, sm = G.gru_forward_octbit(w, mel, seq_len=seq)
+    np.testing.assert_array_equal(lm[1, 4:], np.broadcast_to(w["bfc"], (8, 6)))
+    np.testing.assert_array_equal(sm[:, 2], np.zeros((2, 128), np.float32))
+    # (numpy's BLAS rounds the fp32 layer 0 differently for batch 1 and 3: last-bit input changes, rare q flips)
+    np.testing.assert_allclose(sm[:, 1], G.gru_forward_octbit(w, mel[1:2, :4])[1][:, 0], atol=2e-3)
