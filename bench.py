@@ -224,7 +224,8 @@ def main():
                                            "int8": "u8 x s8 -> sat i16 -> i32, layer 0 f32 (secondary line; headline is f32)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[1]: 2xGRU h=128 n_mel=40 6-class, %d concurrent streams/GPU x %d frames "
-                                   "per step, fp32, state carried on device, logits+softmax+fused ctc_decode2" % (B, T),
+                                   "per step, %s, state carried on device, logits+softmax+fused ctc_decode2"
+                                   % (B, T, {"fp32": "fp32", "bf16": "configs[2] bf16 variant", "int8": "configs[2] octbit int8 variant"}[args.precision]),
                        "streams_per_gpu": B, "frames_per_step": T, "parallelism": "utterance-dp%d" % world,
                        "kernel": model.kernel},
             "realtime_streams": value / 100.0,

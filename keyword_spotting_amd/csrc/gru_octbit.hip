@@ -42,14 +42,7 @@ __device__ __forceinline__ void scalar_cache_invalidate() {
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// acc += sat16(ae.lo*we.lo + ao.lo*wo.lo) + sat16(ae.hi*we.hi + ao.hi*wo.hi)   (ae, ao wave-uniform).
-// volatile: keeps the SMEM issue / wait / compute order exactly as written (a plain asm floats across the waits)
-__device__ __forceinline__ int pair2_s(int acc, uint32_t ae, uint32_t ao, uint32_t we, uint32_t wo, uint32_t ones) {
-    uint32_t t;
-    asm volatile("v_pk_mul_lo_u16 %1, %2, %4\n\tv_pk_mad_i16 %1, %3, %5, %1 clamp\n\tv_dot2_i32_i16 %0, %1, %6, %0"
-                 : "+v"(acc), "=&v"(t) : "s"(ae), "s"(ao), "v"(we), "v"(wo), "v"(ones));
-    return acc;
-}
+// pair arithmetic: acc += sat16(ae.lo*we.lo + ao.lo*wo.lo) + sat16(ae.hi*we.hi + ao.hi*wo.hi)
 // same with per-lane activations (class projection)
 __device__ __forceinline__ int pair2_v(int acc, uint32_t ae, uint32_t ao, uint32_t we, uint32_t wo, uint32_t ones) {
     uint32_t p, s;
@@ -59,12 +52,34 @@ __device__ __forceinline__ int pair2_v(int acc, uint32_t ae, uint32_t ao, uint32
     return acc;
 }
 
+// four couples in one statement: the compiler separates consecutive asm statements with an s_nop
+__device__ __forceinline__ int pair8_s(int acc, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5,
+                                       uint32_t a6, uint32_t a7, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
+                                       uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, uint32_t ones) {
+    uint32_t t;
+    asm volatile(
+        "v_pk_mul_lo_u16 %1, %2, %10\n\tv_pk_mad_i16 %1, %3, %11, %1 clamp\n\tv_dot2_i32_i16 %0, %1, %18, %0\n\t"
+        "v_pk_mul_lo_u16 %1, %4, %12\n\tv_pk_mad_i16 %1, %5, %13, %1 clamp\n\tv_dot2_i32_i16 %0, %1, %18, %0\n\t"
+        "v_pk_mul_lo_u16 %1, %6, %14\n\tv_pk_mad_i16 %1, %7, %15, %1 clamp\n\tv_dot2_i32_i16 %0, %1, %18, %0\n\t"
+        "v_pk_mul_lo_u16 %1, %8, %16\n\tv_pk_mad_i16 %1, %9, %17, %1 clamp\n\tv_dot2_i32_i16 %0, %1, %18, %0"
+        : "+v"(acc), "=&v"(t)
+        : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7),
+          "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7), "v"(ones));
+    return acc;
+}
+
 template <int OFF>
 __device__ __forceinline__ int dot16(int acc, const u32x16& v0, const u32x16& v1, const uint32_t* W, uint32_t ones) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc = pair2_s(acc, v0[2 * c], v0[2 * c + 1], W[OFF + 2 * c], W[OFF + 2 * c + 1], ones);
+    for (int c = 0; c < 2; ++c)
+        acc = pair8_s(acc, v0[8 * c], v0[8 * c + 1], v0[8 * c + 2], v0[8 * c + 3], v0[8 * c + 4], v0[8 * c + 5], v0[8 * c + 6],
+                      v0[8 * c + 7], W[OFF + 8 * c], W[OFF + 8 * c + 1], W[OFF + 8 * c + 2], W[OFF + 8 * c + 3],
+                      W[OFF + 8 * c + 4], W[OFF + 8 * c + 5], W[OFF + 8 * c + 6], W[OFF + 8 * c + 7], ones);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc = pair2_s(acc, v1[2 * c], v1[2 * c + 1], W[OFF + 16 + 2 * c], W[OFF + 16 + 2 * c + 1], ones);
+    for (int c = 0; c < 2; ++c)
+        acc = pair8_s(acc, v1[8 * c], v1[8 * c + 1], v1[8 * c + 2], v1[8 * c + 3], v1[8 * c + 4], v1[8 * c + 5], v1[8 * c + 6],
+                      v1[8 * c + 7], W[OFF + 16 + 8 * c], W[OFF + 16 + 8 * c + 1], W[OFF + 16 + 8 * c + 2], W[OFF + 16 + 8 * c + 3],
+                      W[OFF + 16 + 8 * c + 4], W[OFF + 16 + 8 * c + 5], W[OFF + 16 + 8 * c + 6], W[OFF + 16 + 8 * c + 7], ones);
     return acc;
 }
 
@@ -83,9 +98,14 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
     return a - b;
 }
 
-// octbit_mat_mul_op.cc:105-124 on one value; `off` = 127 (signed branch) or 0
+// octbit_mat_mul_op.cc:105-124 on one value; `off` = 127 (signed branch) or 0.  (A reciprocal-multiply fast
+// path with an exact fallback near half-integers was measured: no gain, the division is not what the stage costs.)
 __device__ __forceinline__ uint32_t quant_u8(float v, float bscale, float off) {
+#ifdef KWS_OABL_NODIV
+    const float r = roundf(v * bscale);
+#else
     const float r = roundf(v / bscale);                 // C round(): half away from zero, on the float quotient
+#endif
     return bscale == 0.f ? 0u : (uint32_t)(int)(r + off) & 0xffu;
 }
 
@@ -186,13 +206,23 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
 
     load_x(0);
     __syncthreads();
+#ifdef KWS_TIMING
+    unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl_ = __builtin_readcyclecounter();
+#define OCT_TS(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); \
+    ph_[i] += tn_ - tl_; tl_ = tn_; asm volatile("" ::: "memory"); } while (0)
+#else
+#define OCT_TS(i) do {} while (0)
+#endif
 
     for (int t = 0; t < T; ++t) {
         if (t > 0) store_out(t - 1);
         // ---- gates: quantise [x, h], exchange, dot, finalize ----------------------------------------
         quantise(0);
+        OCT_TS(0);
         __syncthreads();                                   // stores complete (vmcnt 0) and visible in L2
         scalar_cache_invalidate();
+        OCT_TS(1);
         {
             const uint32_t* base = p.aq + ((size_t)G * 2 + 0) * 16 * 128 + 64 * kh;
             u32x16 a0, a1, b0, b1;
@@ -200,15 +230,25 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
             for (int s = 0; s < 16; ++s) {
                 swait(a0, a1);
                 sload32(base + s * 128 + 32, b0, b1);
+#ifdef KWS_OABL_NODOT
+                int acc = a0[0] + WA[0];
+#else
                 int acc = dot16<0>(0, a0, a1, WA, ones);
+#endif
                 swait(b0, b1);
                 sload32(base + (s < 15 ? s + 1 : 15) * 128, a0, a1);
+#ifdef KWS_OABL_NODOT
+                acc += b0[0] + WA[32];
+#else
                 acc = dot16<32>(acc, b0, b1, WA, ones);
+#endif
                 part[(kh * 16 + s) * 256 + 64 * ug + lane] = acc;
             }
             swait(a0, a1);
         }
+        OCT_TS(2);
         lds_barrier();
+        OCT_TS(3);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int s = sA0 + j;
@@ -221,12 +261,16 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
             if (nA < 128) rh[s * kHS + nA] = mul_rn(a, hs[s * kHS + nA]);
             else ub[s * kHS + nA - 128] = a;
         }
+        OCT_TS(4);
         lds_barrier();
+        OCT_TS(5);
         // ---- candidate: quantise [x, r (.) h], exchange, dot, finalize + state update ---------------
         quantise(1);
         if (t + 1 < T) load_x(t + 1);                      // x of this frame is consumed
+        OCT_TS(6);
         __syncthreads();
         scalar_cache_invalidate();
+        OCT_TS(7);
         {
             const uint32_t* base = p.aq + ((size_t)G * 2 + 1) * 16 * 128 + 32 * kq;
             u32x16 a0, a1, b0, b1;
@@ -234,16 +278,26 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
             for (int s = 0; s < 16; s += 2) {
                 swait(a0, a1);
                 sload32(base + (s + 1) * 128, b0, b1);
+#ifdef KWS_OABL_NODOT
+                int acc = a0[0] + WB[0];
+#else
                 int acc = dot16<0>(0, a0, a1, WB, ones);
+#endif
                 part[(kq * 16 + s) * 128 + 64 * uc + lane] = acc;
                 swait(b0, b1);
                 sload32(base + (s < 14 ? s + 2 : 15) * 128, a0, a1);
+#ifdef KWS_OABL_NODOT
+                acc = b0[0] + WB[1];
+#else
                 acc = dot16<0>(0, b0, b1, WB, ones);
+#endif
                 part[(kq * 16 + s + 1) * 128 + 64 * uc + lane] = acc;
             }
             swait(a0, a1);
         }
+        OCT_TS(8);
         lds_barrier();
+        OCT_TS(9);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int s = sB0 + j;
@@ -257,8 +311,14 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
             const float hn = add_rn(mul_rn(u, hp), mul_rn(sub_rn(1.0f, u), cand));
             if (t < slen[s]) hs[s * kHS + nB] = hn;
         }
+        OCT_TS(10);
         lds_barrier();
+        OCT_TS(11);
     }
+#ifdef KWS_TIMING
+    if (p.dbg && lane == 0)
+        for (int i = 0; i < 12; ++i) p.dbg[((size_t)G * 8 + w) * 12 + i] = ph_[i];
+#endif
     store_out(T - 1);
     for (int i = tid; i < 16 * 128; i += 512) {
         const int s = i >> 7, n = i & 127;

@@ -592,8 +592,31 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             op.state_in = p.state_in; op.state_out = p.state_out;
             op.seq_len = seq_len; op.reset = reset_mask;
             op.aq = h->oct_aq; op.B = B; op.T = T;
+#ifdef KWS_TIMING
+            static unsigned long long* odbg = nullptr;
+            if (!odbg) hipMalloc(reinterpret_cast<void**>(&odbg), (size_t)4096 * 8 * 12 * 8);
+            op.dbg = (B + 15) / 16 <= 4096 ? odbg : nullptr;
+#endif
             e = kws::launch_gru_layer_octbit(op, st);
             if (e != hipSuccess) return hip_fail(e, "launch gru_layer_octbit");
+#ifdef KWS_TIMING
+            {
+                static int dumped = 0;
+                if (op.dbg && h->profiling && dumped++ == 2) {
+                    hipDeviceSynchronize();
+                    std::vector<unsigned long long> hb((size_t)4096 * 8 * 12);
+                    hipMemcpy(hb.data(), op.dbg, hb.size() * 8, hipMemcpyDeviceToHost);
+                    static const char* nm[12] = {"quant0", "sync+inv", "dotA", "bar", "finA", "bar", "quant1", "sync+inv", "dotB", "bar", "finB", "bar"};
+                    for (int gi : {0, 100}) for (int wv : {0, 5}) {
+                        if (gi >= (B + 15) / 16) continue;
+                        fprintf(stderr, "OCT TIMING group %d wave %d per-frame cycles:", gi, wv);
+                        double tot = 0;
+                        for (int i = 0; i < 12; ++i) { const double v = (double)hb[((size_t)gi * 8 + wv) * 12 + i] / T; tot += v; fprintf(stderr, " %s %.0f", nm[i], v); }
+                        fprintf(stderr, " | total %.0f\n", tot);
+                    }
+                }
+            }
+#endif
         } else {
             e = resident ? kws::launch_gru_layer_resident(p, first, last, st)
                          : kws::launch_gru_layer_generic(p, H, first, last, st);

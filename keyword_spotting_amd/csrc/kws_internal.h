@@ -76,6 +76,7 @@ struct GruOctbitParams {
     const uint8_t* reset;
     uint32_t* aq;           // activation exchange [G][2][16 streams][128 dwords]
     int B, T;
+    unsigned long long* dbg;  // timing-variant builds only (-DKWS_TIMING)
 };
 struct OctbitFcParams {
     const uint32_t* wfc;    // [8 tiles][4 g][kMaxClasses][even,odd] int16 pairs

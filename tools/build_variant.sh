@@ -6,5 +6,5 @@ ROOT=$(cd $(dirname $0)/.. && pwd)
 OUT=$ROOT/variants; mkdir -p $OUT
 C=$ROOT/keyword_spotting_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$ROOT/include -I$C -Wno-unused-value -Wno-unused-result "$@" \
-  $C/gru_kernels.hip $C/gru_bf16.hip $C/frontend_kernels.hip $C/stream_kernels.hip $C/decode_kernels.hip $C/octbit_kernels.hip $C/kws_api.hip -o $OUT/libkws_$NAME.so
+  $C/gru_kernels.hip $C/gru_bf16.hip $C/gru_octbit.hip $C/frontend_kernels.hip $C/stream_kernels.hip $C/decode_kernels.hip $C/octbit_kernels.hip $C/kws_api.hip -o $OUT/libkws_$NAME.so
 echo built $OUT/libkws_$NAME.so
