@@ -732,8 +732,8 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
     if (!out) return fail(KWS_ERR_INVALID_ARGUMENT, "out handle pointer is null");
     *out = nullptr;
     if (!cfg) return fail(KWS_ERR_INVALID_ARGUMENT, "config is null");
-    if (cfg->fft_size < 16 || cfg->fft_size > 4096 || cfg->fft_size % 16 != 0)
-        return fail(KWS_ERR_UNSUPPORTED, "fft_size=%d must be a multiple of 16 in [16,4096]", cfg->fft_size);
+    if (cfg->fft_size < 16 || cfg->fft_size > 496 || cfg->fft_size % 16 != 0)
+        return fail(KWS_ERR_UNSUPPORTED, "fft_size=%d must be a multiple of 16 in [16,496] (the reference uses 400)", cfg->fft_size);
     if (cfg->hop_size < 1 || cfg->n_mel < 1 || cfg->n_mel > 64 || cfg->samplerate < 1)
         return fail(KWS_ERR_INVALID_ARGUMENT, "bad hop_size/n_mel/samplerate (%d/%d/%d)", cfg->hop_size, cfg->n_mel, cfg->samplerate);
     if (!(cfg->fmin >= 0.f) || !(cfg->fmax > cfg->fmin) || cfg->fmax > cfg->samplerate / 2.0f + 1e-3f)
@@ -750,7 +750,7 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
     f->basis = slaney_mel_basis(cfg->samplerate, N, cfg->n_mel, cfg->fmin, cfg->fmax);
     std::vector<float> host;
     f->dft_off = 0;
-    host.resize((size_t)f->nf_tiles * 2 * KC4 * 64 * 4, 0.f);
+    host.resize((size_t)4 * kws::frontend_units_per_wave(f->nf_tiles) * KC4 * 64 * 4, 0.f);   // zero units pad to 4*UPW
     const double two_pi = 6.283185307179586476925286766559;
     for (int tile = 0; tile < f->nf_tiles; ++tile)
         for (int cs = 0; cs < 2; ++cs)
@@ -806,12 +806,12 @@ int kws_frontend_run(kws_frontend_handle h, const float* pcm, int B, int n_sampl
     const int T = kws_frontend_frames(&h->cfg, n_samples);
     if (B == 0 || T == 0) return KWS_OK;
     if (!pcm || !mel) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
-    if (B > 65535) return fail(KWS_ERR_UNSUPPORTED, "B=%d exceeds the grid limit 65535", B);
+    if ((long long)B * T > (1LL << 36)) return fail(KWS_ERR_UNSUPPORTED, "B*T=%lld frames exceed the grid limit", (long long)B * T);
     kws::FrontendParams p;
     p.pcm = pcm; p.mel = mel;
     p.dft = h->d_tables + h->dft_off; p.melw = h->d_tables + h->melw_off;
     p.n_samples = n_samples; p.T = T; p.fft = h->cfg.fft_size; p.hop = h->cfg.hop_size; p.n_mel = h->cfg.n_mel;
-    p.nf_tiles = h->nf_tiles; p.mel_tiles = h->mel_tiles; p.kc4 = h->kc4;
+    p.nf_tiles = h->nf_tiles; p.mel_tiles = h->mel_tiles; p.kc4 = h->kc4; p.B = B;
     hipError_t e = kws::launch_mel_frontend(p, B, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "launch mel_frontend");
     return KWS_OK;

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Front-end alone: B streams x one 3600+240-sample chunk -> mel; prints ms per call (HIP events)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from keyword_spotting_amd import get_config
+from keyword_spotting_amd.frontend import MelFrontend
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 3840
+fe = MelFrontend(get_config())
+pcm = torch.randn(B, N, device="cuda") * 0.1
+for _ in range(5): mel = fe.forward(pcm)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(50): mel = fe.forward(pcm)
+b.record(); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 50
+print("front-end B=%d samples=%d -> T=%d: %.3f ms per call, %.1f M frames/s" % (B, N, mel.shape[1], ms, B * mel.shape[1] / ms / 1e3))
