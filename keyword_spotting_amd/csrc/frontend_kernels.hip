@@ -4,56 +4,56 @@
 //   melspec = linearspec @ mel_basis^T        models/rnn_ctc.py:139-149 (librosa.filters.mel, Slaney, area-normalised)
 //
 // One workgroup = kFT x 16 = 64 frames of the FLATTENED [B*T] frame index (a 22-frame chunk wastes nothing, and
-// the cos/sin table, 346 KB that every workgroup streams from L2, is read once per 64 frames instead of once per
-// 16: the first version was L2-bandwidth-bound at 8.7 TB/s).  The DFT is a dense fp32 contraction on
+// the cos/sin table that every workgroup streams from L2 is read once per 64 frames: the first version, 16 frames
+// per workgroup, was L2-bandwidth-bound at 8.7 TB/s).  The DFT is a dense fp32 contraction on
 // v_mfma_f32_16x16x4_f32 with D[bin][frame]: A = cos / sin rows in group-of-4 fragment order, B = the frames.
-// Real input: with e[n] = x[n] + x[N-n], o[n] = x[n] - x[N-n] (0 < n < N/2), e[0] = x[0], e[N/2] = x[N/2]:
-//   Re X[k] = sum_{n<=N/2} e[n] cos(2 pi k n / N),   Im X[k] = -sum_{n<N/2} o[n] sin(2 pi k n / N)
-// so both contractions run over N/2 (+1) samples instead of N -- half the MFMAs; the fold happens while the
-// windows are staged into LDS (row stride odd: conflict-free column reads).  Work units are (bin tile, cos|sin):
-// 26 for fft 400, dealt round-robin to the four waves (7/7/6/6; even waves only ever read e, odd waves only o).
-// Re^2 and Im^2 meet in LDS in the xl layout (kws_internal.h), which is directly the B operand of the mel
-// projection -- no transpose.  A radix-16x25 two-stage factorisation would cut the matrix work a further ~2.5x.
+// Two exact reductions of the matrix work, N = fft, NH = N/2, NQ = N/4:
+//  * real input (fold):  e[n] = x[n] + x[N-n], o[n] = x[n] - x[N-n] (0 < n < NH), e[0] = x[0], e[NH] = x[NH]:
+//        Re X[k] = sum_{n<=NH} e[n] cos(2 pi k n / N),   Im X[k] = -sum_{n<NH} o[n] sin(2 pi k n / N)
+//  * bin mirror (one radix-2 step): cos(2 pi (NH-k) n / N) = (-1)^n cos(2 pi k n / N), and the sine likewise up to
+//    sign, so with the sums split by the parity of n,  C0/C1 (cos, n even/odd) and S0/S1 (sin):
+//        |X[k]|^2 = (C0+C1)^2 + (S0+S1)^2,     |X[NH-k]|^2 = (C0-C1)^2 + (S0-S1)^2        for k = 0..NQ
+//    -- only bins 0..NQ are contracted, each over half the samples.
+// Work units are (bin tile, cos|sin, parity): 4 per bin tile, so wave w owns ONE (cos|sin, parity) combination
+// for every tile (7 units for fft 400) and reads one of the four folded arrays E0/E1/O0/O1 only.  The partial
+// sums meet in LDS in the xl layout (kws_internal.h); the magnitudes of bins k and NH-k are written back in that
+// same layout and are directly the B operands of the mel projection, whose basis fragments exist in a direct and a
+// mirrored set -- no transpose anywhere.  A further radix step (k, NQ-k, ...) would halve the matrix work again;
+// staging and the mel stage are now as expensive as the DFT itself.
 #include "gru_device.h"
 
 namespace kws {
 
 constexpr int kFT = 4;      // frame tiles (of 16) per workgroup
 #ifndef KWS_FE_SF
-#define KWS_FE_SF 8
+#define KWS_FE_SF 4
 #endif
 constexpr int kSF = KWS_FE_SF;   // frames staged per round and wave
-constexpr int kMaxUPW = 8;  // (bin tile, cos|sin) units per wave: 2 * nf_tiles <= 32, i.e. fft <= 496
 
-// UPW = ceil(2 * nf_tiles / 4): the table is zero-padded to 4 * UPW units so that the unit loop carries no
-// predicate (with one, hipcc keeps the accumulators in VGPRs, copies them through AGPRs around every unit and
-// drains vmcnt(0) -- i.e. the table prefetch -- before each group of MFMAs)
+// UPW = bin tiles over k = 0..NQ (= units per wave).  No predicate in the unit loop: with one, hipcc keeps the
+// accumulators in VGPRs, copies them through AGPRs around every unit and drains vmcnt(0) before each MFMA group.
 template <int UPW>
 __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams p) {
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, g = lane >> 4, f = lane & 15;
-    const int N = p.fft, HOP = p.hop, NFT = p.nf_tiles;
-    const int NH = N / 2;                    // folded length (cos part also uses sample NH)
-    const int KC4 = p.kc4;                   // groups of 16 folded samples: ceil((NH+1)/16)
+    const int N = p.fft, HOP = p.hop;
+    const int NH = N / 2, NQ = N / 4;
+    const int KC4 = p.kc4;                   // groups of 16 samples of one parity class: ceil((NQ+1)/16) == UPW
     const int stride = 16 * KC4 + 1;         // odd
     const long long total = (long long)p.B * p.T;
     const long long f0 = (long long)blockIdx.x * (16 * kFT);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xe = reinterpret_cast<float*>(smem);                  // [64][stride] even part
-    float* xo = xe + 16 * kFT * stride;                          // [64][stride] odd part
-    f32x4* sq = reinterpret_cast<f32x4*>(smem);                  // after the DFT: [NFT][cos|sin][kFT][64] squares
+    float* X = reinterpret_cast<float*>(smem);                   // [4: E0 E1 O0 O1][64 frames][stride]
+    f32x4* P = reinterpret_cast<f32x4*>(smem);                   // after the DFT: [4*UPW units][kFT][64] partial sums
+    const int asz = 16 * kFT * stride;
 
     // stage + fold: wave w takes frames 16w..16w+15, kSF frames per round with all 8*kSF loads of the round in
-    // flight (a load -> fold -> store loop exposes the full memory latency 64 times per wave)
-    const int NS = 16 * KC4;                 // <= 256 for fft <= 496: at most 4 samples per lane and frame
-#ifdef KWS_FE_NOSTAGE
-    for (int i0 = 0; i0 < 0; i0 += kSF) {
-#else
+    // flight (a load -> fold -> store loop exposes the full memory latency once per element)
+#ifndef KWS_FE_NOSTAGE
     for (int i0 = 0; i0 < 16; i0 += kSF) {
-#endif
-        float xa[kSF][4], xc[kSF][4];
+        float xa[kSF][2][2], xc[kSF][2][2];
         bool ok[kSF];
 #pragma unroll
         for (int i = 0; i < kSF; ++i) {
@@ -63,39 +63,48 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
             const int t = ok[i] ? (int)(fidx - b * p.T) : 0;
             const float* x = p.pcm + (size_t)b * p.n_samples + (size_t)t * HOP;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {          // unconditional loads at clamped addresses: no branches, no waits
-                const int n = lane + 64 * q;
-                const int na = n <= NH ? n : NH;
-                xa[i][q] = x[na];
-                xc[i][q] = x[na == 0 ? 0 : N - na];
+            for (int q = 0; q < 2; ++q) {          // unconditional loads at clamped addresses: no branches, no waits
+                const int m = lane + 64 * q, mc = m <= NQ ? m : NQ;
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    int n = 2 * mc + par;
+                    n = n <= NH ? n : NH;
+                    xa[i][q][par] = x[n];
+                    xc[i][q][par] = x[n == 0 ? 0 : N - n];
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < kSF; ++i) {
             const int fr = 16 * w + i0 + i;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = lane + 64 * q;
-                if (n < NS) {
-                    const bool in = ok[i] && n <= NH, edge = n == 0 || n == NH;
-                    xe[fr * stride + n] = in ? (edge ? xa[i][q] : xa[i][q] + xc[i][q]) : 0.f;
-                    xo[fr * stride + n] = (in && !edge) ? xa[i][q] - xc[i][q] : 0.f;
+            for (int q = 0; q < 2; ++q) {
+                const int m = lane + 64 * q;
+                if (m < 16 * KC4) {
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        const int n = 2 * m + par;
+                        const bool in = ok[i] && n <= NH, edge = n == 0 || n == NH;
+                        const float a = xa[i][q][par], c = xc[i][q][par];
+                        X[(0 + par) * asz + fr * stride + m] = in ? (edge ? a : a + c) : 0.f;
+                        X[(2 + par) * asz + fr * stride + m] = (in && !edge) ? a - c : 0.f;
+                    }
                 }
             }
         }
     }
+#endif
     __syncthreads();
 
-    // DFT over the folded samples: units w, w+4, ... ; all of one wave's units are cos (even w) or sin (odd w)
-    const int cs = w & 1;
+    // DFT: wave w = (cos|sin = w >> 1, parity = w & 1), units u = 4 * tile + w
     f32x4 acc[UPW][kFT];
 #pragma unroll
     for (int j = 0; j < UPW; ++j)
 #pragma unroll
         for (int ft = 0; ft < kFT; ++ft) acc[j][ft] = splat4(0.f);
     const f32x4* dft = reinterpret_cast<const f32x4*>(p.dft) + (size_t)w * KC4 * 64 + lane;   // [4*UPW units][KC4][64]
-    const size_t ustride = (size_t)4 * KC4 * 64;                                                // unit u = w + 4j = 2*tile + cs
-    const float* src = (cs ? xo : xe) + f * stride + g;
+    const size_t ustride = (size_t)4 * KC4 * 64;
+    const float* src = X + w * asz + f * stride + g;
     // table fragments ping-pong between two register sets, one k4 group ahead (pinned: left alone, hipcc sinks the
     // loads to the end of the iteration and waits vmcnt(0) on them at once)
     f32x4 a0[UPW], a1[UPW];
@@ -135,57 +144,60 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
 #endif
 #pragma unroll
     for (int j = 0; j < UPW; ++j) asm volatile("s_nop 15" : "+a"(acc[j][0]), "+a"(acc[j][1]), "+a"(acc[j][2]), "+a"(acc[j][3]));
-    __syncthreads();                       // every wave is done with the windows: the squares reuse their space
+    __syncthreads();                       // every wave is done with the windows: the partial sums reuse their space
 #pragma unroll
-    for (int j = 0; j < UPW; ++j) {
-        const int u = w + 4 * j;
-        if (u < 2 * NFT) {
+    for (int j = 0; j < UPW; ++j)
 #pragma unroll
-            for (int ft = 0; ft < kFT; ++ft) sq[((size_t)u * kFT + ft) * 64 + lane] = acc[j][ft] * acc[j][ft];
-        }
+        for (int ft = 0; ft < kFT; ++ft) P[((size_t)(4 * j + w) * kFT + ft) * 64 + lane] = acc[j][ft];
+    __syncthreads();
+
+    // butterfly + magnitudes, once, by all four waves: slot 4t+0 <- |X[k]|, slot 4t+1 <- |X[NH-k]|
+    // (v_sqrt_f32, 1 ulp: an IEEE sqrtf sequence per element cost more than the whole DFT)
+    for (int i = w; i < UPW * kFT; i += 4) {
+        const int t = i / kFT, ft = i - t * kFT;
+        f32x4* q = P + ((size_t)(4 * t) * kFT + ft) * 64 + lane;
+        const f32x4 c0 = q[0], c1 = q[kFT * 64], s0 = q[2 * kFT * 64], s1 = q[3 * kFT * 64];
+        const f32x4 rp = c0 + c1, rm = c0 - c1, ip = s0 + s1, im = s0 - s1;
+        const f32x4 d2 = rp * rp + ip * ip, m2 = rm * rm + im * im;
+        f32x4 d, m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d[e] = __builtin_amdgcn_sqrtf(d2[e]); m[e] = __builtin_amdgcn_sqrtf(m2[e]); }
+        q[0] = d;
+        q[kFT * 64] = m;
     }
     __syncthreads();
 
-    // magnitudes once, by all four waves, in place of the Re^2 slot (v_sqrt_f32: 1 ulp; an IEEE sqrtf sequence
-    // per element, repeated by every mel-tile wave, cost more than the whole DFT)
-    for (int i = w; i < NFT * kFT; i += 4) {
-        const int nt = i / kFT, ft = i - nt * kFT;
-        const f32x4 s2 = sq[((size_t)(2 * nt) * kFT + ft) * 64 + lane] + sq[((size_t)(2 * nt + 1) * kFT + ft) * 64 + lane];
-        f32x4 m;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = __builtin_amdgcn_sqrtf(s2[e]);
-        sq[((size_t)(2 * nt) * kFT + ft) * 64 + lane] = m;
-    }
-    __syncthreads();
-    // mel projection: wave w = mel tile w over all frame tiles; B operand = the magnitudes in xl layout.  The
-    // basis fragments of the tile are fetched in groups of 4 bin tiles ahead of their use (a load per chunk
-    // inside the loop exposes the L2 latency 13 times)
+    // mel projection: wave w = mel tile w over all frame tiles; B operands = the two magnitude blocks in xl layout,
+    // A = the direct / mirrored basis fragments, fetched two bin tiles ahead of their use
 #ifndef KWS_FE_NOMEL
     if (w < p.mel_tiles) {
         f32x4 o[kFT];
 #pragma unroll
         for (int ft = 0; ft < kFT; ++ft) o[ft] = splat4(0.f);
-        const float* melw = p.melw + (size_t)w * (4 * NFT) * 64 + lane;           // [mel tile][4*NFT chunks][64]
+        const float* melw = p.melw + (size_t)w * (8 * UPW) * 64 + lane;           // [mel tile][UPW][direct|mirror][4][64]
         float mw[16], mn[16];
-        auto fetch_mel = [&](float (&m)[16], int nt0) {
+        auto fetch_mel = [&](float (&mm)[16], int t0) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const int ch = 4 * nt0 + c;
-                m[c] = melw[(size_t)(ch < 4 * NFT ? ch : 4 * NFT - 1) * 64];
+                const int ch = 8 * t0 + c;
+                mm[c] = melw[(size_t)(ch < 8 * UPW ? ch : 8 * UPW - 1) * 64];
             }
         };
         fetch_mel(mw, 0);
-        for (int nt0 = 0; nt0 < NFT; nt0 += 4) {
-            fetch_mel(mn, nt0 + 4);
+        for (int t0 = 0; t0 < UPW; t0 += 2) {
+            fetch_mel(mn, t0 + 2);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nt = nt0 + q;
-                if (nt < NFT) {
+            for (int q = 0; q < 2; ++q) {
+                const int t = t0 + q;
+                if (t < UPW) {
 #pragma unroll
                     for (int ft = 0; ft < kFT; ++ft) {
-                        const f32x4 m = sq[((size_t)(2 * nt) * kFT + ft) * 64 + lane];
+                        const f32x4 d = P[((size_t)(4 * t) * kFT + ft) * 64 + lane];
+                        const f32x4 m = P[((size_t)(4 * t + 1) * kFT + ft) * 64 + lane];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[ft] = mfma4(mw[4 * q + e], m[e], o[ft]);
+                        for (int e = 0; e < 4; ++e) o[ft] = mfma4(mw[8 * q + e], d[e], o[ft]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[ft] = mfma4(mw[8 * q + 4 + e], m[e], o[ft]);
                     }
                 }
             }
@@ -219,16 +231,14 @@ static hipError_t launch_upw(const FrontendParams& p, unsigned grid, size_t lds,
     return hipGetLastError();
 }
 
-int frontend_units_per_wave(int nf_tiles) { return (2 * nf_tiles + 3) / 4; }
-
 hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st) {
     const int stride = 16 * p.kc4 + 1;
-    const size_t windows = (size_t)2 * 16 * kFT * stride * 4;
-    const size_t squares = (size_t)p.nf_tiles * 2 * kFT * 64 * 16;
-    const size_t lds = windows > squares ? windows : squares;
+    const size_t windows = (size_t)4 * 16 * kFT * stride * 4;
+    const size_t sums = (size_t)4 * p.nf_tiles * kFT * 64 * 16;
+    const size_t lds = windows > sums ? windows : sums;
     const long long total = (long long)B * p.T;
     const unsigned grid = (unsigned)((total + 16 * kFT - 1) / (16 * kFT));
-    switch (frontend_units_per_wave(p.nf_tiles)) {
+    switch (p.nf_tiles) {
         case 1: return launch_upw<1>(p, grid, lds, st);
         case 2: return launch_upw<2>(p, grid, lds, st);
         case 3: return launch_upw<3>(p, grid, lds, st);

@@ -743,40 +743,48 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
     kws_frontend* f = new (std::nothrow) kws_frontend();
     if (!f) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
     f->cfg = *cfg;
-    const int N = cfg->fft_size, NF = N / 2 + 1, KC4 = (N / 2 + 1 + 15) / 16;   // folded samples 0..N/2
+    // frontend_kernels.hip: bins k = 0..N/4 are contracted, each over the even and the odd folded samples
+    const int N = cfg->fft_size, NF = N / 2 + 1, NH = N / 2, NQ = N / 4, TILES = (NQ + 1 + 15) / 16, KC4 = TILES;
     f->kc4 = KC4;
-    f->nf_tiles = (NF + 15) / 16;
+    f->nf_tiles = TILES;
     f->mel_tiles = (cfg->n_mel + 15) / 16;
     f->basis = slaney_mel_basis(cfg->samplerate, N, cfg->n_mel, cfg->fmin, cfg->fmax);
     std::vector<float> host;
     f->dft_off = 0;
-    host.resize((size_t)4 * kws::frontend_units_per_wave(f->nf_tiles) * KC4 * 64 * 4, 0.f);   // zero units pad to 4*UPW
+    host.resize((size_t)4 * TILES * KC4 * 64 * 4, 0.f);
     const double two_pi = 6.283185307179586476925286766559;
-    for (int tile = 0; tile < f->nf_tiles; ++tile)
-        for (int cs = 0; cs < 2; ++cs)
+    for (int tile = 0; tile < TILES; ++tile)
+        for (int a = 0; a < 4; ++a)                      // a = 2 * (cos|sin) + parity of n
             for (int k4 = 0; k4 < KC4; ++k4)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 4; ++e) {
-                        const int g = lane >> 4, i = lane & 15;
-                        const int bin = 16 * tile + i, n = 4 * (4 * k4 + e) + g;
+                        const int g = lane >> 4, i = lane & 15, cs = a >> 1, par = a & 1;
+                        const int bin = 16 * tile + i, m = 4 * (4 * k4 + e) + g, n = 2 * m + par;
                         float v = 0.f;
                         // cos rows use folded samples 0..N/2, sin rows 1..N/2-1 (sin vanishes at 0 and N/2)
-                        if (bin < NF && n <= N / 2 && !(cs == 1 && (n == 0 || n == N / 2))) {
+                        if (bin <= NQ && n <= NH && !(cs == 1 && (n == 0 || n == NH))) {
                             const double ang = two_pi * (double)(((long long)bin * n) % N) / N;
                             v = (float)(cs == 0 ? std::cos(ang) : std::sin(ang));
                         }
-                        host[((((size_t)(tile * 2 + cs) * KC4 + k4) * 64 + lane) * 4) + e] = v;
+                        host[((((size_t)(4 * tile + a) * KC4 + k4) * 64 + lane) * 4) + e] = v;
                     }
+    // mel basis fragments, xl k map over k = 0..N/4: direct set basis[m][k], mirrored set basis[m][N/2 - k] (k < N/4)
     f->melw_off = host.size();
-    host.resize(host.size() + (size_t)f->mel_tiles * 4 * f->nf_tiles * 64, 0.f);
+    host.resize(host.size() + (size_t)f->mel_tiles * TILES * 8 * 64, 0.f);
     for (int mt = 0; mt < f->mel_tiles; ++mt)
-        for (int kc = 0; kc < 4 * f->nf_tiles; ++kc)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int g = lane >> 4, i = lane & 15;
-                const int bin = 16 * (kc / 4) + 4 * g + (kc % 4), m = 16 * mt + i;
-                host[f->melw_off + ((size_t)mt * 4 * f->nf_tiles + kc) * 64 + lane] =
-                    (bin < NF && m < cfg->n_mel) ? f->basis[(size_t)m * NF + bin] : 0.f;
-            }
+        for (int t = 0; t < TILES; ++t)
+            for (int mir = 0; mir < 2; ++mir)
+                for (int e = 0; e < 4; ++e)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 4, i = lane & 15;
+                        const int k = 16 * t + 4 * g + e, m = 16 * mt + i;
+                        float v = 0.f;
+                        if (m < cfg->n_mel) {
+                            if (mir == 0 && k <= NQ) v = f->basis[(size_t)m * NF + k];
+                            if (mir == 1 && k < NQ) v = f->basis[(size_t)m * NF + (NH - k)];
+                        }
+                        host[f->melw_off + ((((size_t)mt * TILES + t) * 2 + mir) * 4 + e) * 64 + lane] = v;
+                    }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_tables), host.size() * sizeof(float));
     if (e != hipSuccess) { delete f; return hip_fail(e, "hipMalloc(frontend tables)"); }
     e = hipMemcpy(f->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);

@@ -115,12 +115,11 @@ hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st);
 struct FrontendParams {
     const float* pcm;    // [B, n_samples]
     float* mel;          // [B, T, n_mel]
-    const float* dft;    // [4*UPW units = nf_tiles x (cos|sin), zero padded][kc4][64][4]  A fragments over the FOLDED samples n = 0..fft/2, k map n = 4*kc + g
-    const float* melw;   // [mel_tiles][4*nf_tiles][64]         A fragments of the mel basis, xl k map over bins
+    const float* dft;    // [nf_tiles x (cos|sin) x parity][kc4][64][4]  A fragments: bins 0..fft/4 over the folded samples of one parity
+    const float* melw;   // [mel_tiles][nf_tiles][direct|mirror][4][64]  A fragments of the mel basis, xl k map over k = 0..fft/4
     int n_samples, T, fft, hop, n_mel, nf_tiles, mel_tiles, kc4, B;
 };
 hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st);
-int frontend_units_per_wave(int nf_tiles);   // the cos/sin table is zero-padded to 4x this many units
 
 // launchers (gru_kernels.hip)
 bool gru_resident_supported(int hidden, int in_dim, bool first);
