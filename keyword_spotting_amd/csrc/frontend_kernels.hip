@@ -52,16 +52,17 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
     // stage + fold: wave w takes frames 16w..16w+15, kSF frames per round with all 8*kSF loads of the round in
     // flight (a load -> fold -> store loop exposes the full memory latency once per element)
 #ifndef KWS_FE_NOSTAGE
+    // (stream, frame) of the wave's first frame by one division, then counted up
+    long long sb = (f0 + 16 * w) / p.T;
+    int st = (int)(f0 + 16 * w - sb * p.T);
     for (int i0 = 0; i0 < 16; i0 += kSF) {
         float xa[kSF][2][2], xc[kSF][2][2];
         bool ok[kSF];
 #pragma unroll
         for (int i = 0; i < kSF; ++i) {
-            const long long fidx = f0 + 16 * w + i0 + i;
-            ok[i] = fidx < total;
-            const long long b = ok[i] ? fidx / p.T : 0;
-            const int t = ok[i] ? (int)(fidx - b * p.T) : 0;
-            const float* x = p.pcm + (size_t)b * p.n_samples + (size_t)t * HOP;
+            ok[i] = f0 + 16 * w + i0 + i < total;
+            const float* x = p.pcm + (ok[i] ? (size_t)sb * p.n_samples + (size_t)st * HOP : 0);
+            if (++st == p.T) { st = 0; ++sb; }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {          // unconditional loads at clamped addresses: no branches, no waits
                 const int m = lane + 64 * q, mc = m <= NQ ? m : NQ;
