@@ -16,8 +16,12 @@
 //
 // Mapping.  16 streams per workgroup (B = 4096 fills the 256 CUs exactly as the fp32 kernels do), 8 waves.
 // lane = output unit: each lane keeps the int16-expanded weights of ITS unit in VGPRs for the whole launch
-// (64 dwords for the gates' K-half + 32 for the candidate's K-quarter), so the activation operand is the
-// same for all 64 lanes -- a wave-uniform value, i.e. an SGPR operand.  The quantised activations of the
+// (two units x K-quarter = 64 dwords for the gates, two units x K-eighth = 32 for the candidate), so the
+// activation operand is the same for all 64 lanes -- a wave-uniform value, i.e. an SGPR operand.  Two units per
+// lane give 96 VALU instructions per fetched 32-dword batch: scalar loads return out of order, only lgkmcnt(0) is
+// usable, so the prefetch is one batch deep and a batch has to outlast the fetch.  (Measured: one unit per lane
+// with half the work per batch ran at the same speed -- the dot phases are VALU-issue-bound at ~80 % of the
+// 4-cycles-per-instruction ideal, not latency-bound.)  The quantised activations of the
 // group (16 x 512 B per matmul) are written to a small global exchange buffer and fetched back with
 // s_load_dwordx16 (scalar cache, invalidated after each exchange); LDS cannot feed a uniform operand
 // without paying a full 64-lane return per read, which would make LDS the bound by 2.7x.
@@ -68,19 +72,19 @@ __device__ __forceinline__ int pair8_s(int acc, uint32_t a0, uint32_t a1, uint32
     return acc;
 }
 
+// one s_load_dwordx16 worth of activations (8 couples) against the 16 weight dwords W[OFF..OFF+15] of one unit
 template <int OFF>
-__device__ __forceinline__ int dot16(int acc, const u32x16& v0, const u32x16& v1, const uint32_t* W, uint32_t ones) {
+__device__ __forceinline__ int dot8(int acc, const u32x16& v, const uint32_t* W, uint32_t ones) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-        acc = pair8_s(acc, v0[8 * c], v0[8 * c + 1], v0[8 * c + 2], v0[8 * c + 3], v0[8 * c + 4], v0[8 * c + 5], v0[8 * c + 6],
-                      v0[8 * c + 7], W[OFF + 8 * c], W[OFF + 8 * c + 1], W[OFF + 8 * c + 2], W[OFF + 8 * c + 3],
+        acc = pair8_s(acc, v[8 * c], v[8 * c + 1], v[8 * c + 2], v[8 * c + 3], v[8 * c + 4], v[8 * c + 5], v[8 * c + 6],
+                      v[8 * c + 7], W[OFF + 8 * c], W[OFF + 8 * c + 1], W[OFF + 8 * c + 2], W[OFF + 8 * c + 3],
                       W[OFF + 8 * c + 4], W[OFF + 8 * c + 5], W[OFF + 8 * c + 6], W[OFF + 8 * c + 7], ones);
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-        acc = pair8_s(acc, v1[8 * c], v1[8 * c + 1], v1[8 * c + 2], v1[8 * c + 3], v1[8 * c + 4], v1[8 * c + 5], v1[8 * c + 6],
-                      v1[8 * c + 7], W[OFF + 16 + 8 * c], W[OFF + 16 + 8 * c + 1], W[OFF + 16 + 8 * c + 2], W[OFF + 16 + 8 * c + 3],
-                      W[OFF + 16 + 8 * c + 4], W[OFF + 16 + 8 * c + 5], W[OFF + 16 + 8 * c + 6], W[OFF + 16 + 8 * c + 7], ones);
     return acc;
+}
+// two s_load_dwordx16 from two rows
+__device__ __forceinline__ void sload16x2(const uint32_t* p0, const uint32_t* p1, u32x16& a, u32x16& b) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(a), "=&s"(b) : "s"(p0), "s"(p1) : "memory");
 }
 
 // Separately rounded fp32 ops, as the reference's graph executes them (OctbitMatMul output, then BiasAdd, ...).
@@ -122,8 +126,8 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
     float* hs = reinterpret_cast<float*>(smem);          // [16][kHS] recurrent state, fp32
     float* rh = hs + 16 * kHS;                           // r (.) h
     float* ub = rh + 16 * kHS;                           // u
-    int* part = reinterpret_cast<int*>(ub + 16 * kHS);   // partial sums: gates [2][16][256], candidate [4][16][128]
-    float* bsc = reinterpret_cast<float*>(part + 8192);  // [2 matmuls][16]
+    int* part = reinterpret_cast<int*>(ub + 16 * kHS);   // partial sums: gates [4][16][256], candidate [8][16][128]
+    float* bsc = reinterpret_cast<float*>(part + 16384); // [2 matmuls][16]
     int* sgn = reinterpret_cast<int*>(bsc + 32);         // [2][16]
     int* slen = sgn + 32;                                // [16]
 
@@ -133,13 +137,13 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
     const uint32_t ones = 0x00010001u;
 
     // ---- resident weights: this lane's unit, int16-expanded (we,wo) couples -----------------------------
-    const int ug = w & 3, kh = w >> 2;       // gates: units 64ug.., K-half kh
-    const int uc = w & 1, kq = w >> 1;       // candidate: units 64uc.., K-quarter kq
-    uint32_t WA[64], WB[32];
+    const int ug = w & 1, kq = w >> 1;       // gates: units 128ug + {lane, 64 + lane}, K-quarter kq
+    const int k8 = w;                        // candidate: units {lane, 64 + lane}, K-eighth k8
+    uint32_t WA[64], WB[32];                 // [unit-in-lane][couples x (even, odd)]
 #pragma unroll
-    for (int c = 0; c < 64; ++c) WA[c] = p.wg[((size_t)(kh * 4 + ug) * 64 + c) * 64 + lane];
+    for (int c = 0; c < 64; ++c) WA[c] = p.wg[((size_t)(kq * 2 + ug) * 64 + c) * 64 + lane];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) WB[c] = p.wc[((size_t)(kq * 2 + uc) * 32 + c) * 64 + lane];
+    for (int c = 0; c < 32; ++c) WB[c] = p.wc[((size_t)k8 * 32 + c) * 64 + lane];
 
     // finalize mappings
     const int nA = tid & 255, sA0 = 8 * (tid >> 8);
@@ -224,25 +228,27 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
         scalar_cache_invalidate();
         OCT_TS(1);
         {
-            const uint32_t* base = p.aq + ((size_t)G * 2 + 0) * 16 * 128 + 64 * kh;
+            const uint32_t* base = p.aq + ((size_t)G * 2 + 0) * 16 * 128 + 32 * kq;
+            int* dst = part + (kq * 16) * 256 + 128 * ug + lane;
             u32x16 a0, a1, b0, b1;
             sload32(base, a0, a1);
-            for (int s = 0; s < 16; ++s) {
+            for (int s = 0; s < 16; s += 2) {
                 swait(a0, a1);
-                sload32(base + s * 128 + 32, b0, b1);
+                sload32(base + (s + 1) * 128, b0, b1);
 #ifdef KWS_OABL_NODOT
-                int acc = a0[0] + WA[0];
+                dst[s * 256] = a0[0] + WA[0]; dst[s * 256 + 64] = a1[0] + WA[32];
 #else
-                int acc = dot16<0>(0, a0, a1, WA, ones);
+                dst[s * 256] = dot8<16>(dot8<0>(0, a0, WA, ones), a1, WA, ones);
+                dst[s * 256 + 64] = dot8<48>(dot8<32>(0, a0, WA, ones), a1, WA, ones);
 #endif
                 swait(b0, b1);
-                sload32(base + (s < 15 ? s + 1 : 15) * 128, a0, a1);
+                sload32(base + (s < 14 ? s + 2 : 15) * 128, a0, a1);
 #ifdef KWS_OABL_NODOT
-                acc += b0[0] + WA[32];
+                dst[(s + 1) * 256] = b0[0] + WA[1]; dst[(s + 1) * 256 + 64] = b1[0] + WA[33];
 #else
-                acc = dot16<32>(acc, b0, b1, WA, ones);
+                dst[(s + 1) * 256] = dot8<16>(dot8<0>(0, b0, WA, ones), b1, WA, ones);
+                dst[(s + 1) * 256 + 64] = dot8<48>(dot8<32>(0, b0, WA, ones), b1, WA, ones);
 #endif
-                part[(kh * 16 + s) * 256 + 64 * ug + lane] = acc;
             }
             swait(a0, a1);
         }
@@ -252,7 +258,8 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int s = sA0 + j;
-            const int o = part[(0 * 16 + s) * 256 + nA] + part[(1 * 16 + s) * 256 + nA];
+            const int o = (part[(0 * 16 + s) * 256 + nA] + part[(1 * 16 + s) * 256 + nA]) +
+                          (part[(2 * 16 + s) * 256 + nA] + part[(3 * 16 + s) * 256 + nA]);
             float of = (float)o;
             if (sgn[s]) of = sub_rn(of, b127A);                                        // :176 signed correction
             const float sc = mul_rn(p.scale_g, bsc[s]);                  // :108 scale *= bscale
@@ -272,26 +279,31 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
         scalar_cache_invalidate();
         OCT_TS(7);
         {
-            const uint32_t* base = p.aq + ((size_t)G * 2 + 1) * 16 * 128 + 32 * kq;
+            const uint32_t* base = p.aq + ((size_t)G * 2 + 1) * 16 * 128 + 16 * k8;   // one batch = two streams x 16 dwords
+            int* dst = part + (k8 * 16) * 128 + lane;
             u32x16 a0, a1, b0, b1;
-            sload32(base, a0, a1);
-            for (int s = 0; s < 16; s += 2) {
+            sload16x2(base, base + 128, a0, a1);
+            for (int s = 0; s < 16; s += 4) {
                 swait(a0, a1);
-                sload32(base + (s + 1) * 128, b0, b1);
+                sload16x2(base + (s + 2) * 128, base + (s + 3) * 128, b0, b1);
 #ifdef KWS_OABL_NODOT
-                int acc = a0[0] + WB[0];
+                dst[s * 128] = a0[0] + WB[0]; dst[s * 128 + 64] = a0[1] + WB[16]; dst[(s + 1) * 128] = a1[0]; dst[(s + 1) * 128 + 64] = a1[1];
 #else
-                int acc = dot16<0>(0, a0, a1, WB, ones);
+                dst[s * 128] = dot8<0>(0, a0, WB, ones);
+                dst[s * 128 + 64] = dot8<16>(0, a0, WB, ones);
+                dst[(s + 1) * 128] = dot8<0>(0, a1, WB, ones);
+                dst[(s + 1) * 128 + 64] = dot8<16>(0, a1, WB, ones);
 #endif
-                part[(kq * 16 + s) * 128 + 64 * uc + lane] = acc;
                 swait(b0, b1);
-                sload32(base + (s < 14 ? s + 2 : 15) * 128, a0, a1);
+                { const int sn = s < 12 ? s + 4 : 14; sload16x2(base + sn * 128, base + (sn + 1) * 128, a0, a1); }
 #ifdef KWS_OABL_NODOT
-                acc = b0[0] + WB[1];
+                dst[(s + 2) * 128] = b0[0]; dst[(s + 2) * 128 + 64] = b0[1]; dst[(s + 3) * 128] = b1[0]; dst[(s + 3) * 128 + 64] = b1[1];
 #else
-                acc = dot16<0>(0, b0, b1, WB, ones);
+                dst[(s + 2) * 128] = dot8<0>(0, b0, WB, ones);
+                dst[(s + 2) * 128 + 64] = dot8<16>(0, b0, WB, ones);
+                dst[(s + 3) * 128] = dot8<0>(0, b1, WB, ones);
+                dst[(s + 3) * 128 + 64] = dot8<16>(0, b1, WB, ones);
 #endif
-                part[(kq * 16 + s + 1) * 128 + 64 * uc + lane] = acc;
             }
             swait(a0, a1);
         }
@@ -301,8 +313,9 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int s = sB0 + j;
-            const int o = (part[(0 * 16 + s) * 128 + nB] + part[(1 * 16 + s) * 128 + nB]) +
-                          (part[(2 * 16 + s) * 128 + nB] + part[(3 * 16 + s) * 128 + nB]);
+            int o = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o += part[(k * 16 + s) * 128 + nB];
             float of = (float)o;
             if (sgn[16 + s]) of = sub_rn(of, b127B);
             const float sc = mul_rn(p.scale_c, bsc[16 + s]);
@@ -452,7 +465,7 @@ __global__ void __launch_bounds__(512) octbit_fc_kernel(const OctbitFcParams p) 
     }
 }
 
-size_t gru_octbit_lds_bytes() { return (size_t)(3 * 16 * kHS + 8192 + 32 + 32 + 16) * 4; }
+size_t gru_octbit_lds_bytes() { return (size_t)(3 * 16 * kHS + 16384 + 32 + 32 + 16) * 4; }
 
 hipError_t launch_gru_layer_octbit(const GruOctbitParams& p, hipStream_t st) {
     const int groups = (p.B + 15) / 16;

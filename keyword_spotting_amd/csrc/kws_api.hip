@@ -328,29 +328,32 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
                 O.b127 = reserve(3 * (size_t)H);
                 for (int j = 0; j < 2 * H; ++j) host[O.b127 + j] = gb[j];
                 for (int j = 0; j < H; ++j) host[O.b127 + 2 * H + j] = cb[j];
-                O.wg = reserve((size_t)2 * 4 * 64 * 64);
+                // gates: wave (kq, ug) -> [unit-in-lane 2][32 = 16 couples x (even, odd)][64 lanes]
+                O.wg = reserve((size_t)4 * 2 * 64 * 64);
                 {
                     uint32_t* dst = reinterpret_cast<uint32_t*>(&host[O.wg]);
-                    for (int kh = 0; kh < 2; ++kh)
-                        for (int ug = 0; ug < 4; ++ug)
-                            for (int c2 = 0; c2 < 64; ++c2)
+                    for (int kq = 0; kq < 4; ++kq)
+                        for (int ug = 0; ug < 2; ++ug)
+                            for (int c = 0; c < 64; ++c)
                                 for (int lane = 0; lane < 64; ++lane) {
-                                    const int n = 64 * ug + lane, k0 = 128 * kh + 4 * (c2 / 2) + (c2 & 1);
-                                    dst[((size_t)(kh * 4 + ug) * 64 + c2) * 64 + lane] =
+                                    const int ul = c >> 5, c2 = c & 31;
+                                    const int n = 128 * ug + 64 * ul + lane, k0 = 64 * kq + 4 * (c2 / 2) + (c2 & 1);
+                                    dst[((size_t)(kq * 2 + ug) * 64 + c) * 64 + lane] =
                                         pack16(gq[(size_t)n * K + k0], gq[(size_t)n * K + k0 + 2]);
                                 }
                 }
-                O.wc = reserve((size_t)4 * 2 * 32 * 64);
+                // candidate: wave k8 -> [unit-in-lane 2][16 = 8 couples x (even, odd)][64 lanes]
+                O.wc = reserve((size_t)8 * 32 * 64);
                 {
                     uint32_t* dst = reinterpret_cast<uint32_t*>(&host[O.wc]);
-                    for (int kq = 0; kq < 4; ++kq)
-                        for (int uc = 0; uc < 2; ++uc)
-                            for (int c2 = 0; c2 < 32; ++c2)
-                                for (int lane = 0; lane < 64; ++lane) {
-                                    const int n = 64 * uc + lane, k0 = 64 * kq + 4 * (c2 / 2) + (c2 & 1);
-                                    dst[((size_t)(kq * 2 + uc) * 32 + c2) * 64 + lane] =
-                                        pack16(cq[(size_t)n * K + k0], cq[(size_t)n * K + k0 + 2]);
-                                }
+                    for (int k8 = 0; k8 < 8; ++k8)
+                        for (int c = 0; c < 32; ++c)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int ul = c >> 4, c2 = c & 15;
+                                const int n = 64 * ul + lane, k0 = 32 * k8 + 4 * (c2 / 2) + (c2 & 1);
+                                dst[((size_t)k8 * 32 + c) * 64 + lane] =
+                                    pack16(cq[(size_t)n * K + k0], cq[(size_t)n * K + k0 + 2]);
+                            }
                 }
             }
             q = Wc + (size_t)K * H + H;

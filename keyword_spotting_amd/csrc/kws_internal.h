@@ -63,8 +63,8 @@ hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStr
 
 // int8 ("octbit") GRU layers and class projection (gru_octbit.hip)
 struct GruOctbitParams {
-    const uint32_t* wg;     // gates  [2 K-halves][4 unit groups][64 = 32 couples x (even,odd)][64 lanes]  int16 pairs
-    const uint32_t* wc;     // cand.  [4 K-quarters][2 unit groups][32][64 lanes]
+    const uint32_t* wg;     // gates  [4 K-quarters][2 unit groups][2 units per lane][32 = 16 couples x (even,odd)][64 lanes]  int16 pairs
+    const uint32_t* wc;     // cand.  [8 K-eighths][2 units per lane][16][64 lanes]
     const float* bias;      // [3][128] (r, u, c)
     const float* b127;      // [384]  127 * column sums of Wq: gates 256, candidate 128 (octbit_graph.py:202-204)
     float scale_g, scale_c; // octize_weight_int8_signed scales
