@@ -26,6 +26,19 @@ from .prediction import ctc_predict as _ctc_predict
 from .queue import SimpleQueue
 
 
+def buf_to_float(x, n_bytes=2, dtype=torch.float32):
+    """detector.py:40-43 (RingBuffer.get, :74-79): little-endian signed PCM -> float in [-1, 1), scale 2^-(8n-1).
+    Integer tensors stay on their device, so 16-bit PCM crosses PCIe at half the bytes and is widened there
+    (exact: a power-of-two scale)."""
+    x = torch.as_tensor(x)
+    if x.dtype.is_floating_point:
+        return x.to(dtype)
+    want = {2: torch.int16, 4: torch.int32, 1: torch.int8}[n_bytes]
+    if x.dtype != want:
+        raise _lib.InvalidArgumentError(-1, "expected %s PCM for n_bytes=%d, got %s" % (want, n_bytes, x.dtype))
+    return x.to(dtype) * (1.0 / float(1 << (8 * n_bytes - 1)))
+
+
 class ChunkFramer(object):
     """Sample bookkeeping of detector.py:179-183: how many frames a PCM chunk yields once the carried
     tail of the previous chunk is prepended, and how many samples are carried forward."""
@@ -202,10 +215,12 @@ class StreamManager(object):
         return self.hit
 
     def feed_pcm(self, pcm_chunk, frontend):
-        chunk = torch.as_tensor(pcm_chunk, dtype=torch.float32)
+        """pcm_chunk [B, n]: float samples, or int16 PCM as the sound card delivers it (converted on the device
+        by buf_to_float, detector.py:74-79)."""
+        chunk = torch.as_tensor(pcm_chunk)
         if chunk.dim() == 1:
             chunk = chunk.unsqueeze(0)
-        chunk = chunk.to(self.model.device)
+        chunk = buf_to_float(chunk.to(self.model.device))
         data = chunk if self.res is None else torch.cat([self.res, chunk], 1)
         fft, hop = self.config.fft_size, self.config.hop_size
         n = int(data.shape[1])

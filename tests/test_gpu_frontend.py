@@ -121,3 +121,24 @@ def test_frontend_argument_errors():
     cfg, fe = _frontend()
     with pytest.raises(_lib.InvalidArgumentError, match="rank 2"):
         fe.forward(torch.zeros(2, 3, 400))
+
+
+def test_stream_manager_accepts_int16_pcm_like_the_ring_buffer():
+    """detector.py:40-43,74-79: the sound card's int16 samples are scaled by 2^-15 -- here on the device; the
+    result equals feeding the host-converted floats, chunk by chunk, bit for bit."""
+    from keyword_spotting_amd.detector import StreamManager, buf_to_float
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg, fe = _frontend()
+    w = G.init_weights()
+    w["Wfc"] = (w["Wfc"] * 3).astype(np.float32)
+    rng = np.random.default_rng(221)
+    pcm16 = (rng.standard_normal((5, 3600 * 6)) * 4000).clip(-32768, 32767).astype(np.int16)
+    as_float = (1.0 / 32768.0) * pcm16.astype(np.float32)                       # buf_to_float of the reference
+    np.testing.assert_array_equal(buf_to_float(torch.from_numpy(pcm16)).numpy(), as_float)
+    a, b = StreamManager(DeployModel(cfg, w), 5, label="12"), StreamManager(DeployModel(cfg, w), 5, label="12")
+    for c in range(6):
+        ha = a.feed_pcm(torch.from_numpy(pcm16[:, 3600 * c:3600 * (c + 1)]).cuda(), fe).clone()
+        hb = b.feed_pcm(torch.from_numpy(as_float[:, 3600 * c:3600 * (c + 1)]), fe).clone()
+        assert torch.equal(ha, hb) and torch.equal(a.state, b.state)
+    with pytest.raises(ValueError):
+        buf_to_float(torch.zeros(4, dtype=torch.int32))
