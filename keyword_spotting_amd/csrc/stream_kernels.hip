@@ -5,17 +5,23 @@
 //   * concatenate the window, ctc_decode2, ctc_predict(label) (detector.py:197-201) -> windowed re-scan,
 //     exactly the reference's O(window) decode (not an incremental approximation)
 //   * on trigger: clear the window and request a state reset (detector.py:202-208) -> restart[b] = 1
-// One wave per stream (kws_window_step_kernel below).
+// One wave per stream (window_step_kernel below).
 #include "kws_internal.h"
 
 namespace kws {
 
-// One wave per stream: lanes = frames for the per-frame rule and for moving the ring through LDS with every load in
-// flight; the FIFO walk + label match is inherently sequential but short (<= nq*tmax bytes) and runs on lane 0.
+// One wave per stream, all 64 lanes busy: the per-frame rule, the ring's trip through LDS, the FIFO concatenation,
+// the change-point compaction (ballot + popcount keeps the order) and the label match (every start position in
+// parallel).  ctc_predict only asks whether the label occurs in the emitted words, so "first hit wins" in the
+// reference's loop and "any hit" here are the same decision.  (A lane-0 replay of the window took 61 us for 4096
+// streams: ~400 cycles per frame of single-lane, latency-bound code.)
 __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int NQ = p.nq, TM = p.tmax, C = p.C;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];       // [NQ][TM] words of this stream
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* ring = lds;                    // [NQ][TM] words of this stream
+    unsigned char* seq = ring + NQ * TM;          // the window concatenated in FIFO order
+    unsigned char* emit = seq + NQ * TM;          // emitted words (1-based), compacted
     int head = p.head[b], count = p.count[b];
     if (p.clear_before && p.clear_before[b]) { head = 0; count = 0; }
     // add(): drop the oldest chunk when full (utils/queue.py:26-32)
@@ -31,9 +37,21 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
         int arg = 0;
         for (int c = 2; c < C - 1; ++c)
             if (row[c] > best) { best = row[c]; arg = c - 1; }
-        const int8_t wd = (int8_t)(best > p.thres ? arg : -1);
-        gring[slot * TM + t] = wd;
+        gring[slot * TM + t] = (int8_t)(best > p.thres ? arg : -1);
     }
+    // chunk lengths in FIFO order: lane q holds chunk q, then an exclusive prefix over the <= 15 lanes
+    int len = 0;
+    if (lane < count) {
+        const int sl = (head + lane) % NQ;
+        len = sl == slot ? p.T : p.lens[b * NQ + sl];
+    }
+    int incl = len;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    const int total = __shfl(incl, count - 1);
     // ring -> LDS, 16 bytes per lane per trip (the new chunk's bytes come from the stores above: same wave, so
     // wait for them and read back through the cache)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -42,30 +60,41 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
     for (int i = lane; i < nvec; i += 64)
         reinterpret_cast<uint4*>(ring)[i] = reinterpret_cast<const uint4*>(gring)[i];
     __syncthreads();
+    // concatenate (detector.py:197): chunk q goes to seq[off_q ...)
+    for (int q = 0; q < count; ++q) {
+        const int lq = __shfl(len, q), off = __shfl(incl, q) - lq, sl = (head + q) % NQ;
+        for (int t = lane; t < lq; t += 64) seq[off + t] = ring[sl * TM + t];
+    }
+    __syncthreads();
+    // emit on word changes (utils/prediction.py:76-80), compacted in order
+    int n_emit = 0;
+    for (int base = 0; base < total; base += 64) {
+        const int pos = base + lane;
+        bool flag = false;
+        int wd = -1;
+        if (pos < total) {
+            wd = (int)(signed char)seq[pos];
+            const int pw = pos > 0 ? (int)(signed char)seq[pos - 1] : -1;
+            flag = wd >= 0 && wd != pw;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+        if (flag) emit[n_emit + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned char)(wd + 1);
+        n_emit += __builtin_popcountll(m);
+    }
+    __syncthreads();
+    // ctc_predict (utils/prediction.py:111-118): is the label a substring of the emitted words?
+    bool found = false;
+    const int L = p.label_len;
+    for (int base = 0; base + L <= n_emit && !found; base += 64) {
+        const int i = base + lane;
+        bool ok = i + L <= n_emit;
+        for (int j = 0; j < L && ok; ++j) ok = (int)emit[i + j] == p.label[j];
+        found = __builtin_amdgcn_ballot_w64(ok) != 0ull;
+    }
+    const int hit = (found || L == 0) ? 1 : 0;
     if (lane == 0) {
         p.lens[b * NQ + slot] = p.T;
-        // concatenate the window in FIFO order, emit on word changes, match the label at the tail of what was
-        // emitted: the emitted words (1..9) are shifted into a 64-bit register, 4 bits each
-        unsigned long long want = 0ull, mask = 0ull;
-        for (int j = 0; j < p.label_len; ++j) { want = (want << 4) | (unsigned)p.label[j]; mask = (mask << 4) | 0xfull; }
-        unsigned long long hist = 0ull;
-        int prev = -1, hit = 0, nh = 0;
-        for (int q = 0; q < count && !hit; ++q) {
-            const int sl = (head + q) % NQ;
-            const int len = p.lens[b * NQ + sl];
-            const unsigned char* chunk = ring + sl * TM;
-            for (int t = 0; t < len && !hit; ++t) {
-                const int wd = (int)(signed char)chunk[t];
-                if (wd >= 0 && wd != prev) {
-                    hist = (hist << 4) | (unsigned)(wd + 1);
-                    ++nh;
-                    hit = (nh >= p.label_len && ((hist ^ want) & mask) == 0ull) ? 1 : 0;
-                }
-                prev = wd;
-            }
-        }
-        if (p.label_len == 0) hit = 1;
-        if (hit) { head = 0; count = 0; }
+        if (hit) { head = 0; count = 0; }        // detector.py:202-208
         p.head[b] = head;
         p.count[b] = count;
         p.hit[b] = hit;
@@ -79,7 +108,7 @@ __global__ void window_reset_kernel(int B, int* head, int* count) {
 }
 
 hipError_t launch_window_step(const WindowParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(window_step_kernel, dim3(p.B), dim3(64), (size_t)p.nq * p.tmax, st, p);
+    hipLaunchKernelGGL(window_step_kernel, dim3(p.B), dim3(64), (size_t)3 * p.nq * p.tmax, st, p);
     return hipGetLastError();
 }
 hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st) {
