@@ -150,6 +150,12 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
 int kws_frontend_destroy(kws_frontend_handle h);
 int kws_frontend_frames(const kws_frontend_config* cfg, int n_samples);
 int kws_frontend_run(kws_frontend_handle h, const float* pcm, int B, int n_samples, float* mel, void* stream);
+/* The streaming form (detector.py:179-183): the signal of stream b is carry[b] followed by chunk[b] --
+ * np.concatenate((self.res, data)) -- read in place, never materialised; mel [B,T,n_mel] with
+ * T = kws_frontend_frames(n_carry + n_chunk) (nothing is written when that is 0).  Also writes next_carry [B,n_next],
+ * the last n_next samples of that signal (self.res = data[-res:]); it must not overlap carry or chunk. */
+int kws_frontend_run_carry(kws_frontend_handle h, const float* carry, int n_carry, const float* chunk, int n_chunk,
+                           int B, float* mel, float* next_carry, int n_next, void* stream);
 /* Copies the fp32 mel basis [n_mel, fft/2+1] (host memory) the handle was built with -- for inspection/tests. */
 int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host);
 

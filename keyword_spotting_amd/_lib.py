@@ -62,6 +62,7 @@ _SIGNATURES = {
     "kws_frontend_destroy": (_i, [_vp]),
     "kws_frontend_frames": (_i, [ctypes.POINTER(KwsFrontendConfig), _i]),
     "kws_frontend_run": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "kws_frontend_run_carry": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "kws_frontend_mel_basis": (_i, [_vp, _vp]),
     "kws_window_create": (_i, [_i, _i, _i, _i, _f, ctypes.POINTER(_vp)]),
     "kws_window_destroy": (_i, [_vp]),

@@ -61,17 +61,39 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
 #pragma unroll
         for (int i = 0; i < kSF; ++i) {
             ok[i] = f0 + 16 * w + i0 + i < total;
-            const float* x = p.pcm + (ok[i] ? (size_t)sb * p.n_samples + (size_t)st * HOP : 0);
+            // the signal of stream sb is carry[sb] (n_carry samples, may be 0) followed by pcm[sb] (detector.py:179)
+            const long long row = ok[i] ? sb : 0;
+            const float* xc_ = p.carry + (size_t)row * p.n_carry;
+            const float* xp_ = p.pcm + (size_t)row * (p.n_samples - p.n_carry);
+            const int s0 = ok[i] ? st * HOP : 0;
             if (++st == p.T) { st = 0; ++sb; }
+            // only the first frames of a chunk straddle the seam; every other frame reads one array (uniform branch)
+            const bool seam = s0 < p.n_carry && s0 + N > p.n_carry;
+            if (!seam) {
+                const float* x = s0 >= p.n_carry ? xp_ + (s0 - p.n_carry) : xc_ + s0;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {          // unconditional loads at clamped addresses: no branches, no waits
-                const int m = lane + 64 * q, mc = m <= NQ ? m : NQ;
+                for (int q = 0; q < 2; ++q) {          // unconditional loads at clamped addresses: no branches, no waits
+                    const int m = lane + 64 * q, mc = m <= NQ ? m : NQ;
 #pragma unroll
-                for (int par = 0; par < 2; ++par) {
-                    int n = 2 * mc + par;
-                    n = n <= NH ? n : NH;
-                    xa[i][q][par] = x[n];
-                    xc[i][q][par] = x[n == 0 ? 0 : N - n];
+                    for (int par = 0; par < 2; ++par) {
+                        int n = 2 * mc + par;
+                        n = n <= NH ? n : NH;
+                        xa[i][q][par] = x[n];
+                        xc[i][q][par] = x[n == 0 ? 0 : N - n];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int m = lane + 64 * q, mc = m <= NQ ? m : NQ;
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        int n = 2 * mc + par;
+                        n = n <= NH ? n : NH;
+                        const int ia = s0 + n, ic = s0 + (n == 0 ? 0 : N - n);
+                        xa[i][q][par] = ia < p.n_carry ? xc_[ia] : xp_[ia - p.n_carry];
+                        xc[i][q][par] = ic < p.n_carry ? xc_[ic] : xp_[ic - p.n_carry];
+                    }
                 }
             }
         }
@@ -217,6 +239,22 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
         }
     }
 #endif
+}
+
+// next carry = the last n_next samples of [carry | chunk]   (detector.py:181-183)
+__global__ void __launch_bounds__(256) carry_tail_kernel(const float* __restrict__ carry, int n_carry, const float* __restrict__ chunk,
+                                                         int n_chunk, float* __restrict__ next, int n_next) {
+    const int b = blockIdx.y;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_next; j += gridDim.x * 256) {
+        const int i = n_carry + n_chunk - n_next + j;
+        next[(size_t)b * n_next + j] = i < n_carry ? carry[(size_t)b * n_carry + i] : chunk[(size_t)b * n_chunk + i - n_carry];
+    }
+}
+hipError_t launch_carry_tail(const float* carry, int n_carry, const float* chunk, int n_chunk, float* next, int n_next, int B,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(carry_tail_kernel, dim3((n_next + 255) / 256 > 0 ? (n_next + 255) / 256 : 1, B), dim3(256), 0, st, carry, n_carry,
+                       chunk, n_chunk, next, n_next);
+    return hipGetLastError();
 }
 
 template <int UPW>

@@ -811,20 +811,48 @@ int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host) {
     return KWS_OK;
 }
 
-int kws_frontend_run(kws_frontend_handle h, const float* pcm, int B, int n_samples, float* mel, void* stream) {
-    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
-    if (B < 0 || n_samples < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative dimension");
+static int frontend_run_impl(kws_frontend_handle h, const float* carry, int n_carry, const float* chunk, int n_chunk, int B,
+                             float* mel, void* stream) {
+    const int n_samples = n_carry + n_chunk;
     const int T = kws_frontend_frames(&h->cfg, n_samples);
     if (B == 0 || T == 0) return KWS_OK;
-    if (!pcm || !mel) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (!chunk || !mel || (n_carry > 0 && !carry)) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
     if ((long long)B * T > (1LL << 36)) return fail(KWS_ERR_UNSUPPORTED, "B*T=%lld frames exceed the grid limit", (long long)B * T);
     kws::FrontendParams p;
-    p.pcm = pcm; p.mel = mel;
+    p.pcm = chunk; p.carry = n_carry > 0 ? carry : chunk; p.mel = mel;
     p.dft = h->d_tables + h->dft_off; p.melw = h->d_tables + h->melw_off;
-    p.n_samples = n_samples; p.T = T; p.fft = h->cfg.fft_size; p.hop = h->cfg.hop_size; p.n_mel = h->cfg.n_mel;
+    p.n_samples = n_samples; p.n_carry = n_carry; p.T = T; p.fft = h->cfg.fft_size; p.hop = h->cfg.hop_size; p.n_mel = h->cfg.n_mel;
     p.nf_tiles = h->nf_tiles; p.mel_tiles = h->mel_tiles; p.kc4 = h->kc4; p.B = B;
     hipError_t e = kws::launch_mel_frontend(p, B, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "launch mel_frontend");
+    return KWS_OK;
+}
+
+int kws_frontend_run(kws_frontend_handle h, const float* pcm, int B, int n_samples, float* mel, void* stream) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (B < 0 || n_samples < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative dimension");
+    return frontend_run_impl(h, nullptr, 0, pcm, n_samples, B, mel, stream);
+}
+
+int kws_frontend_run_carry(kws_frontend_handle h, const float* carry, int n_carry, const float* chunk, int n_chunk, int B,
+                           float* mel, float* next_carry, int n_next, void* stream) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (B < 0 || n_carry < 0 || n_chunk < 0 || n_next < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative dimension");
+    if (n_next > n_carry + n_chunk) return fail(KWS_ERR_INVALID_ARGUMENT, "n_next=%d exceeds the %d available samples", n_next, n_carry + n_chunk);
+    if (n_next > 0 && !next_carry) return fail(KWS_ERR_INVALID_ARGUMENT, "next_carry is null");
+    if (B == 0) return KWS_OK;
+    if (n_chunk > 0 && !chunk) return fail(KWS_ERR_INVALID_ARGUMENT, "chunk is null");
+    if (n_carry > 0 && !carry) return fail(KWS_ERR_INVALID_ARGUMENT, "carry is null");
+    if (n_carry + n_chunk >= h->cfg.fft_size) {
+        if (!mel) return fail(KWS_ERR_INVALID_ARGUMENT, "mel is null");
+        const int rc = frontend_run_impl(h, carry, n_carry, chunk, n_chunk, B, mel, stream);
+        if (rc != KWS_OK) return rc;
+    }
+    if (n_next > 0) {
+        hipError_t e = kws::launch_carry_tail(carry ? carry : chunk, n_carry, chunk ? chunk : carry, n_chunk, next_carry, n_next, B,
+                                              static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return hip_fail(e, "launch carry_tail");
+    }
     return KWS_OK;
 }
 

@@ -113,13 +113,16 @@ hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st);
 
 // PCM -> mel front-end (frontend_kernels.hip)
 struct FrontendParams {
-    const float* pcm;    // [B, n_samples]
+    const float* pcm;    // [B, n_samples - n_carry]  the new samples
+    const float* carry;  // [B, n_carry] samples carried over from the previous chunk (n_carry may be 0)
     float* mel;          // [B, T, n_mel]
     const float* dft;    // [nf_tiles x (cos|sin) x parity][kc4][64][4]  A fragments: bins 0..fft/4 over the folded samples of one parity
     const float* melw;   // [mel_tiles][nf_tiles][direct|mirror][4][64]  A fragments of the mel basis, xl k map over k = 0..fft/4
-    int n_samples, T, fft, hop, n_mel, nf_tiles, mel_tiles, kc4, B;
+    int n_samples, T, fft, hop, n_mel, nf_tiles, mel_tiles, kc4, B, n_carry;   // n_samples = n_carry + new samples
 };
 hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st);
+hipError_t launch_carry_tail(const float* carry, int n_carry, const float* chunk, int n_chunk, float* next, int n_next, int B,
+                             hipStream_t st);
 
 // launchers (gru_kernels.hip)
 bool gru_resident_supported(int hidden, int in_dim, bool first);

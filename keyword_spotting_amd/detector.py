@@ -221,13 +221,13 @@ class StreamManager(object):
         if chunk.dim() == 1:
             chunk = chunk.unsqueeze(0)
         chunk = buf_to_float(chunk.to(self.model.device))
-        data = chunk if self.res is None else torch.cat([self.res, chunk], 1)
         fft, hop = self.config.fft_size, self.config.hop_size
-        n = int(data.shape[1])
+        n = int(chunk.shape[1]) + (0 if self.res is None else int(self.res.shape[1]))
+        # detector.py:179-183 without materialising np.concatenate((self.res, data)): the front-end reads the
+        # carried samples and the chunk in place and hands back the next carry
+        keep = n if n < fft else (n - fft) % hop + (fft - hop)
+        mel, self.res = frontend.forward_carry(self.res, chunk, keep)
         if n < fft:
-            self.res = data
             self.hit.zero_()
             return self.hit
-        keep = (n - fft) % hop + (fft - hop)
-        self.res = data[:, n - keep:].contiguous()
-        return self.feed(frontend.forward(data.contiguous()), pcm_chunk=chunk)
+        return self.feed(mel, pcm_chunk=chunk)

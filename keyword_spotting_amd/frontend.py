@@ -57,3 +57,19 @@ class MelFrontend(object):
             _lib.check(self._lib.kws_frontend_run(self._handle, _lib.ptr(x), b, n, _lib.ptr(mel),
                                                   _lib.current_stream_ptr()))
         return mel[0] if single else mel
+
+    def forward_carry(self, carry, chunk, n_next):
+        """Streaming form (detector.py:179-183): mel of [carry | chunk] without building the concatenation, and the
+        next carry (its last n_next samples).  carry [B,n_c] or None, chunk [B,n] float32 device tensors."""
+        chunk = chunk.contiguous()
+        b, n = int(chunk.shape[0]), int(chunk.shape[1])
+        nc = 0 if carry is None else int(carry.shape[1])
+        if carry is not None:
+            carry = carry.contiguous()
+        t = self.num_frames(nc + n)
+        mel = torch.empty(b, t, self.config.n_mel, dtype=torch.float32, device=self.device)
+        nxt = torch.empty(b, int(n_next), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.kws_frontend_run_carry(self._handle, _lib.ptr(carry) if nc else None, nc, _lib.ptr(chunk), n, b,
+                                                        _lib.ptr(mel), _lib.ptr(nxt), int(n_next), _lib.current_stream_ptr()))
+        return mel, nxt

@@ -142,3 +142,36 @@ def test_stream_manager_accepts_int16_pcm_like_the_ring_buffer():
         assert torch.equal(ha, hb) and torch.equal(a.state, b.state)
     with pytest.raises(ValueError):
         buf_to_float(torch.zeros(4, dtype=torch.int32))
+
+
+def test_carry_form_equals_concatenation_and_streams_like_the_host_loop():
+    """kws_frontend_run_carry reads [carry | chunk] in place: same mel bits as the materialised concatenation, same
+    next carry as data[-res:] (detector.py:179-183); StreamManager.feed_pcm built on it fires like HotwordDetector."""
+    from keyword_spotting_amd.detector import HotwordDetector, StreamManager
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg, fe = _frontend()
+    rng = np.random.default_rng(231)
+    for b, nc, n, keep in ((3, 240, 3600, 320), (5, 320, 3600, 240), (2, 0, 3600, 240), (4, 399, 1, 400), (1, 100, 50, 150)):
+        carry = torch.from_numpy(rng.standard_normal((b, nc)).astype(np.float32)).cuda()
+        chunk = torch.from_numpy(rng.standard_normal((b, n)).astype(np.float32)).cuda()
+        mel, nxt = fe.forward_carry(carry if nc else None, chunk, keep)
+        data = torch.cat([carry, chunk], 1)
+        assert torch.equal(nxt, data[:, data.shape[1] - keep:])
+        if nc + n >= cfg.fft_size:
+            assert torch.equal(mel, fe.forward(data))
+        else:
+            assert mel.shape[1] == 0
+    w = G.init_weights()
+    w["Wfc"] = (w["Wfc"] * 3).astype(np.float32)
+    det = HotwordDetector(DeployModel(cfg, w), batch=3, label="12")
+    mgr = StreamManager(DeployModel(cfg, w), 3, label="12")
+    pcm = (rng.standard_normal((3, 40000)) * 0.2).astype(np.float32)
+    pos = 0
+    for n in (200, 150, 3600, 3600, 1000, 5000, 3600, 3600, 3600, 3600, 3600, 3600):   # incl. chunks shorter than a frame
+        piece = pcm[:, pos:pos + n]
+        pos += n
+        want = np.zeros(3, np.int32)
+        want[det.feed_pcm(piece, fe)] = 1
+        got = mgr.feed_pcm(torch.from_numpy(piece), fe).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        assert torch.equal(mgr.state, det.state)
