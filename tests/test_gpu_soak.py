@@ -55,3 +55,52 @@ def test_random_shapes_resident_vs_generic_vs_oracle():
             assert np.abs(r["logits"].cpu().numpy() - want_l).max() < 1e-4, (trial, kernel)
             assert np.abs(r["state"].cpu().numpy() - want_s).max() < 1e-4, (trial, kernel)
         assert (outs[0]["logits"] - outs[1]["logits"]).abs().max().item() < 3e-5
+
+
+def test_two_handles_on_two_streams_do_not_interfere():
+    """All work is enqueued on the caller's stream and scratch is per handle: two models stepping concurrently on two
+    HIP streams (different batch / chunk shapes, scratch re-grown mid-way) give the bits of running them alone."""
+    import torch
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    from oracle import gru_oracle as G
+    cfg = get_config()
+    wa, wb = G.random_weights(40, 128, 2, 6, seed=401), G.random_weights(40, 128, 2, 6, seed=402)
+    mela = torch.from_numpy(G.synthetic_mel(200, 64, 40, seed=403)).cuda()
+    melb = torch.from_numpy(G.synthetic_mel(77, 90, 40, seed=404)).cuda()
+
+    def run(model, mel, chunks, stream=None):
+        st, pos, outs = model.zero_state(mel.shape[0]), 0, []
+        for n in chunks:
+            if stream is None:
+                r = model.forward(mel[:, pos:pos + n].contiguous(), st)
+            else:
+                with torch.cuda.stream(stream):
+                    r = model.forward(mel[:, pos:pos + n].contiguous(), st)
+            st, pos = r["state"], pos + n
+            outs.append(r["logits"])
+        return outs, st
+
+    ca, cb = [5, 22, 23, 14], [30, 1, 59]
+    ref_a, sa = run(DeployModel(cfg, wa), mela, ca)
+    ref_b, sb = run(DeployModel(cfg, wb), melb, cb)
+    torch.cuda.synchronize()
+    ma, mb = DeployModel(cfg, wa), DeployModel(cfg, wb)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+    sta, stb = ma.zero_state(200), mb.zero_state(77)
+    got_a, got_b, pa, pb = [], [], 0, 0
+    for i in range(max(len(ca), len(cb))):          # interleave the two streams chunk by chunk
+        if i < len(ca):
+            with torch.cuda.stream(s1):
+                r = ma.forward(mela[:, pa:pa + ca[i]].contiguous(), sta)
+                sta, pa = r["state"], pa + ca[i]
+                got_a.append(r["logits"])
+        if i < len(cb):
+            with torch.cuda.stream(s2):
+                r = mb.forward(melb[:, pb:pb + cb[i]].contiguous(), stb)
+                stb, pb = r["state"], pb + cb[i]
+                got_b.append(r["logits"])
+    torch.cuda.synchronize()
+    for x, y in zip(ref_a + ref_b + [sa, sb], got_a + got_b + [sta, stb]):
+        assert torch.equal(x, y)
