@@ -518,52 +518,101 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
     const bool vec_ok = (I & 3) == 0;
     __syncthreads();
 
+    // Weight fragments stream from L2 every frame.  One "row" = the fragments of all TPW tiles for one k-group;
+    // rows ping-pong between two register sets, the next row's loads pinned ahead of the current row's MFMAs
+    // (12 TPW MFMAs = 1.5k cycles at TPW = 4, more than an L2 round trip).  Left to hipcc, every tile's three loads
+    // were waited for right before their MFMAs and the kernel ran latency-bound at half the MFMA rate.
+    auto x_operand = [&](int t, int k4) -> f32x4 {
+        f32x4 xb;
+        if (FIRST) {
+            const int k = 16 * k4 + 4 * g;
+            const float* src = xrow + (size_t)t * I + k;
+            if (vec_ok && k + 3 < I) {
+                xb = ld4(src);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[e] = (k + e < I) ? src[e] : 0.f;
+            }
+        } else {
+            xb = xprev[((size_t)t * NT + k4) * 64];
+        }
+        return xb;
+    };
+    struct RowX { f32x4 a[TPW][3]; f32x4 xb; };
+    struct RowH { f32x4 a[TPW][2]; };
+    struct RowC { f32x4 a[TPW]; };
+    auto load_x = [&](RowX& r, int t, int k4) {
+        const int kk = k4 < KCX4 ? k4 : KCX4 - 1;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) r.a[j][q] = wx[(((TPW * w + j) * 3 + q) * KCX4 + kk) * 64 + lane];
+        r.xb = x_operand(t, kk);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_h = [&](RowH& r, int k4) {
+        const int kk = k4 < NT ? k4 : NT - 1;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) r.a[j][q] = wh[(((TPW * w + j) * 3 + q) * NT + kk) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_c = [&](RowC& r, int k4) {
+        const int kk = k4 < NT ? k4 : NT - 1;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) r.a[j] = wh[(((TPW * w + j) * 3 + 2) * NT + kk) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     for (int t = 0; t < T; ++t) {
         f32x4 acc_r[TPW], acc_u[TPW], acc_c[TPW];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; acc_c[j] = bias_c[j]; }
         // x-part (gates and candidate)
-        for (int k4 = 0; k4 < KCX4; ++k4) {
-            f32x4 xb;
-            if (FIRST) {
-                const int k = 16 * k4 + 4 * g;
-                const float* src = xrow + (size_t)t * I + k;
-                if (vec_ok && k + 3 < I) {
-                    xb = ld4(src);
-                } else {
+        {
+            auto mma = [&](const RowX& r) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xb[e] = (k + e < I) ? src[e] : 0.f;
-                }
-            } else {
-                xb = xprev[((size_t)t * NT + k4) * 64];
-            }
+                for (int j = 0; j < TPW; ++j)
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                const int n = TPW * w + j;
-                const f32x4 ar = wx[((n * 3 + 0) * KCX4 + k4) * 64 + lane];
-                const f32x4 au = wx[((n * 3 + 1) * KCX4 + k4) * 64 + lane];
-                const f32x4 ac = wx[((n * 3 + 2) * KCX4 + k4) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc_r[j] = mfma4(ar[e], xb[e], acc_r[j]);
-                    acc_u[j] = mfma4(au[e], xb[e], acc_u[j]);
-                    acc_c[j] = mfma4(ac[e], xb[e], acc_c[j]);
+                    for (int e = 0; e < 4; ++e) {
+                        acc_r[j] = mfma4(r.a[j][0][e], r.xb[e], acc_r[j]);
+                        acc_u[j] = mfma4(r.a[j][1][e], r.xb[e], acc_u[j]);
+                        acc_c[j] = mfma4(r.a[j][2][e], r.xb[e], acc_c[j]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            RowX ra, rb;
+            load_x(ra, t, 0);
+            for (int k4 = 0; k4 < KCX4; k4 += 2) {
+                load_x(rb, t, k4 + 1);
+                mma(ra);
+                if (k4 + 1 < KCX4) {
+                    load_x(ra, t, k4 + 2);
+                    mma(rb);
                 }
             }
         }
         // gates, h-part
-        for (int k4 = 0; k4 < NT; ++k4) {
-            const f32x4 hb = hbuf[k4 * 64 + lane];
+        {
+            auto mma = [&](const RowH& r, int k4) {
+                const f32x4 hb = hbuf[k4 * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                const int n = TPW * w + j;
-                const f32x4 ar = wh[((n * 3 + 0) * NT + k4) * 64 + lane];
-                const f32x4 au = wh[((n * 3 + 1) * NT + k4) * 64 + lane];
+                for (int j = 0; j < TPW; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc_r[j] = mfma4(ar[e], hb[e], acc_r[j]);
-                    acc_u[j] = mfma4(au[e], hb[e], acc_u[j]);
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        acc_r[j] = mfma4(r.a[j][0][e], hb[e], acc_r[j]);
+                        acc_u[j] = mfma4(r.a[j][1][e], hb[e], acc_u[j]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            RowH ra, rb;
+            load_h(ra, 0);
+            for (int k4 = 0; k4 < NT; k4 += 2) {          // NT is even
+                load_h(rb, k4 + 1);
+                mma(ra, k4);
+                load_h(ra, k4 + 2);
+                mma(rb, k4 + 1);
             }
         }
         f32x4 u[TPW];
@@ -577,15 +626,23 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
             }
             rhbuf[(TPW * w + j) * 64 + lane] = rh;
         }
+        RowC ca, cb;
+        load_c(ca, 0);                 // does not depend on the exchange: issued ahead of the barrier
         __syncthreads();
-        for (int k4 = 0; k4 < NT; ++k4) {
-            const f32x4 rb = rhbuf[k4 * 64 + lane];
+        {
+            auto mma = [&](const RowC& r, int k4) {
+                const f32x4 rb = rhbuf[k4 * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                const int n = TPW * w + j;
-                const f32x4 ac = wh[((n * 3 + 2) * NT + k4) * 64 + lane];
+                for (int j = 0; j < TPW; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc_c[j] = mfma4(ac[e], rb[e], acc_c[j]);
+                    for (int e = 0; e < 4; ++e) acc_c[j] = mfma4(r.a[j][e], rb[e], acc_c[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (int k4 = 0; k4 < NT; k4 += 2) {
+                load_c(cb, k4 + 1);
+                mma(ca, k4);
+                load_c(ca, k4 + 2);
+                mma(cb, k4 + 1);
             }
         }
         const unsigned live = t < len_s ? 0xffffffffu : 0u;
