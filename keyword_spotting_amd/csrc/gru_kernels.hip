@@ -469,13 +469,12 @@ gru_layer_resident(const GruLayerParams p) {
 // Generic kernel: H = 64*TPW, weights streamed from L2 every frame (group-of-4 fragment layout).
 // Same orientation, exchange layout and epilogue; no software pipeline.
 // ------------------------------------------------------------------------------------------------
-template <int TPW, bool FIRST, bool LAST>
-__global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p) {
+template <int TPW, bool FIRST, bool LAST, bool PIPE>
+__device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, const int group) {
     constexpr int NT = 4 * TPW, H = 64 * TPW;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, g = lane >> 4, s = lane & 15;
-    const int group = blockIdx.x;
     const int b_raw = group * kStreamsPerGroup + s;
     const bool bvalid = b_raw < p.B;
     const int b = bvalid ? b_raw : p.B - 1;
@@ -485,20 +484,22 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* hbuf = reinterpret_cast<f32x4*>(smem);
     f32x4* rhbuf = hbuf + NT * 64;
-    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(rhbuf + NT * 64));   // LAST only
+    f32x4* xstage = rhbuf + NT * 64;                                                     // pipelined launch only
+    f32x4* biasl = xstage + NT * 64;                                                      // [3][NT][4 g] bias fragments
+    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * NT * 4));  // LAST only
 
     const f32x4* wx = reinterpret_cast<const f32x4*>(p.wx);   // [NT][3][KCX4][64]
     const f32x4* wh = reinterpret_cast<const f32x4*>(p.wh);   // [NT][3][NT][64]
 
-    f32x4 bias_r[TPW], bias_u[TPW], bias_c[TPW], hreg[TPW];
+    // biases live in LDS (the accumulators are re-initialised from there every frame): at TPW = 4 the 48 registers
+    // they would pin are the difference between fitting the 512-register file and spilling
+    f32x4 hreg[TPW];
     const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
     const int len_s = p.seq_len ? p.seq_len[b] : T;
+    for (int i = tid; i < 3 * NT * 4; i += 256) biasl[i] = ld4(p.bias + 4 * i);   // [gate][tile][g] = bias[gate*H + 16*tile + 4g ..]
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int n = TPW * w + j;
-        bias_r[j] = ld4(p.bias + 0 * H + n * 16 + 4 * g);
-        bias_u[j] = ld4(p.bias + 1 * H + n * 16 + 4 * g);
-        bias_c[j] = ld4(p.bias + 2 * H + n * 16 + 4 * g);
         hreg[j] = do_reset ? splat4(0.f) : ld4(p.state_in + (size_t)b * H + n * 16 + 4 * g);
         hbuf[n * 64 + lane] = hreg[j];
     }
@@ -533,87 +534,124 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xb[e] = (k + e < I) ? src[e] : 0.f;
             }
+        } else if (PIPE) {
+            xb = xstage[k4 * 64 + lane];          // staged at the top of the frame (below)
         } else {
             xb = xprev[((size_t)t * NT + k4) * 64];
         }
         return xb;
     };
-    struct RowX { f32x4 a[TPW][3]; f32x4 xb; };
-    struct RowH { f32x4 a[TPW][2]; };
-    struct RowC { f32x4 a[TPW]; };
-    auto load_x = [&](RowX& r, int t, int k4) {
-        const int kk = k4 < KCX4 ? k4 : KCX4 - 1;
+    // a row covers RT tiles of one k-group: all of the wave's tiles (half rows, RT = 2 at TPW = 4, were measured
+    // 10-15 % slower).  The streaming loops must stay rolled (#pragma nounroll): unrolled, hipcc materialises a
+    // 64-bit address pair per load and the TPW = 4 kernels spill.
+    constexpr int RT = TPW, NP = TPW / RT;
+    struct RowX { f32x4 a[RT][3]; f32x4 xb; };
+    struct RowH { f32x4 a[RT][2]; };
+    struct RowC { f32x4 a[RT]; };
+    auto load_x = [&](RowX& r, int t, int q) {
+        const int qq = q < KCX4 * NP ? q : KCX4 * NP - 1, kk = qq / NP, part = qq - kk * NP;
 #pragma unroll
-        for (int j = 0; j < TPW; ++j)
+        for (int j = 0; j < RT; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) r.a[j][q] = wx[(((TPW * w + j) * 3 + q) * KCX4 + kk) * 64 + lane];
+            for (int c = 0; c < 3; ++c) r.a[j][c] = wx[(((TPW * w + part * RT + j) * 3 + c) * KCX4 + kk) * 64 + lane];
         r.xb = x_operand(t, kk);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto load_h = [&](RowH& r, int k4) {
-        const int kk = k4 < NT ? k4 : NT - 1;
+    auto load_h = [&](RowH& r, int q) {
+        const int qq = q < NT * NP ? q : NT * NP - 1, kk = qq / NP, part = qq - kk * NP;
 #pragma unroll
-        for (int j = 0; j < TPW; ++j)
+        for (int j = 0; j < RT; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) r.a[j][q] = wh[(((TPW * w + j) * 3 + q) * NT + kk) * 64 + lane];
+            for (int c = 0; c < 2; ++c) r.a[j][c] = wh[(((TPW * w + part * RT + j) * 3 + c) * NT + kk) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto load_c = [&](RowC& r, int k4) {
-        const int kk = k4 < NT ? k4 : NT - 1;
+    auto load_c = [&](RowC& r, int q) {
+        const int qq = q < NT * NP ? q : NT * NP - 1, kk = qq / NP, part = qq - kk * NP;
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) r.a[j] = wh[(((TPW * w + j) * 3 + 2) * NT + kk) * 64 + lane];
+        for (int j = 0; j < RT; ++j) r.a[j] = wh[(((TPW * w + part * RT + j) * 3 + 2) * NT + kk) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
     };
-
     for (int t = 0; t < T; ++t) {
         f32x4 acc_r[TPW], acc_u[TPW], acc_c[TPW];
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; acc_c[j] = bias_c[j]; }
-        // x-part (gates and candidate)
+        for (int j = 0; j < TPW; ++j) {
+            const int n = TPW * w + j;
+            acc_r[j] = biasl[(0 * NT + n) * 4 + g]; acc_u[j] = biasl[(1 * NT + n) * 4 + g]; acc_c[j] = biasl[(2 * NT + n) * 4 + g];
+        }
+        if (PIPE && !FIRST) {
+            // layer-pipelined launch: frame t of the layer below must have landed (its workgroup runs concurrently
+            // on another CU).  Every wave polls for itself; the bound turns a protocol bug into a wrong answer plus
+            // an error flag instead of a hung GPU.
+            // Seams and counters live in FINE-GRAINED device memory (uncached in L2, coherent across XCDs), so no
+            // cache-wide acquire is needed -- an agent-scope acquire invalidates the L2 and with it the weight
+            // stream of every workgroup on the XCD, once per frame (measured: slower than the sequential launches).
+            int spins = 0;
+#ifdef KWS_PIPE_NOWAIT
+            if (false)
+#endif
+            while (__hip_atomic_load(p.ready_in + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= t) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 24)) { if (lane == 0) *reinterpret_cast<volatile int*>(p.pipe_error) = 1; break; }
+            }
+            asm volatile("" ::: "memory");
+            // The frame's input block was written by a workgroup on another CU / XCD while this kernel runs:
+            // system-scope (sc0 sc1) loads go past the non-coherent cache levels, dword by dword, at memory
+            // latency -- so the whole block is fetched at once (all loads in flight) and parked in LDS.
+            f32x4 xv[NT / 4];
+#pragma unroll
+            for (int i = 0; i < NT / 4; ++i) {
+                const float* src = reinterpret_cast<const float*>(xprev + ((size_t)t * NT + (w + 4 * i)) * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[i][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+#pragma unroll
+            for (int i = 0; i < NT / 4; ++i) xstage[(w + 4 * i) * 64 + lane] = xv[i];
+            __syncthreads();
+        }
+        // x-part (gates and candidate): rows q = k4 * NP + part, ping-pong, unrolled by two (NP == 2 keeps the parity
+        // of q equal to the part, NP == 1 has a single part)
         {
-            auto mma = [&](const RowX& r) {
-#pragma unroll
-                for (int j = 0; j < TPW; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc_r[j] = mfma4(r.a[j][0][e], r.xb[e], acc_r[j]);
-                        acc_u[j] = mfma4(r.a[j][1][e], r.xb[e], acc_u[j]);
-                        acc_c[j] = mfma4(r.a[j][2][e], r.xb[e], acc_c[j]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            };
+#define KWS_MMA_X(P_)                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < RT; ++j)                                             \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
+                    acc_r[P_ * RT + j] = mfma4(rr.a[j][0][e], rr.xb[e], acc_r[P_ * RT + j]);           \
+                    acc_u[P_ * RT + j] = mfma4(rr.a[j][1][e], rr.xb[e], acc_u[P_ * RT + j]);           \
+                    acc_c[P_ * RT + j] = mfma4(rr.a[j][2][e], rr.xb[e], acc_c[P_ * RT + j]);           \
+                }
             RowX ra, rb;
+            const int NQ = KCX4 * NP;
             load_x(ra, t, 0);
-            for (int k4 = 0; k4 < KCX4; k4 += 2) {
-                load_x(rb, t, k4 + 1);
-                mma(ra);
-                if (k4 + 1 < KCX4) {
-                    load_x(ra, t, k4 + 2);
-                    mma(rb);
+#pragma nounroll
+            for (int q = 0; q < NQ; q += 2) {
+                load_x(rb, t, q + 1);
+                { const RowX& rr = ra; KWS_MMA_X(0); __builtin_amdgcn_sched_barrier(0); }
+                if (q + 1 < NQ) {
+                    load_x(ra, t, q + 2);
+                    { const RowX& rr = rb; if (NP == 2) { KWS_MMA_X((NP - 1)); } else { KWS_MMA_X(0); } __builtin_amdgcn_sched_barrier(0); }
                 }
             }
+#undef KWS_MMA_X
         }
         // gates, h-part
         {
-            auto mma = [&](const RowH& r, int k4) {
-                const f32x4 hb = hbuf[k4 * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < TPW; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc_r[j] = mfma4(r.a[j][0][e], hb[e], acc_r[j]);
-                        acc_u[j] = mfma4(r.a[j][1][e], hb[e], acc_u[j]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            };
+#define KWS_MMA_H(P_)                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < RT; ++j)                                             \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
+                    acc_r[P_ * RT + j] = mfma4(rr.a[j][0][e], hb[e], acc_r[P_ * RT + j]);              \
+                    acc_u[P_ * RT + j] = mfma4(rr.a[j][1][e], hb[e], acc_u[P_ * RT + j]);              \
+                }
             RowH ra, rb;
+            constexpr int NQ = NT * NP;                   // even
             load_h(ra, 0);
-            for (int k4 = 0; k4 < NT; k4 += 2) {          // NT is even
-                load_h(rb, k4 + 1);
-                mma(ra, k4);
-                load_h(ra, k4 + 2);
-                mma(rb, k4 + 1);
+#pragma nounroll
+            for (int q = 0; q < NQ; q += 2) {
+                load_h(rb, q + 1);
+                { const RowH& rr = ra; const f32x4 hb = hbuf[(q / NP) * 64 + lane]; KWS_MMA_H(0); __builtin_amdgcn_sched_barrier(0); }
+                load_h(ra, q + 2);
+                { const RowH& rr = rb; const f32x4 hb = hbuf[((q + 1) / NP) * 64 + lane];
+                  if (NP == 2) { KWS_MMA_H((NP - 1)); } else { KWS_MMA_H(0); } __builtin_amdgcn_sched_barrier(0); }
             }
+#undef KWS_MMA_H
         }
         f32x4 u[TPW];
 #pragma unroll
@@ -630,20 +668,20 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
         load_c(ca, 0);                 // does not depend on the exchange: issued ahead of the barrier
         __syncthreads();
         {
-            auto mma = [&](const RowC& r, int k4) {
-                const f32x4 rb = rhbuf[k4 * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < TPW; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc_c[j] = mfma4(r.a[j][e], rb[e], acc_c[j]);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            for (int k4 = 0; k4 < NT; k4 += 2) {
-                load_c(cb, k4 + 1);
-                mma(ca, k4);
-                load_c(ca, k4 + 2);
-                mma(cb, k4 + 1);
+#define KWS_MMA_C(P_)                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < RT; ++j)                                             \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                          \
+                    acc_c[P_ * RT + j] = mfma4(rr.a[j][e], rb[e], acc_c[P_ * RT + j]);
+            constexpr int NQ = NT * NP;
+#pragma nounroll
+            for (int q = 0; q < NQ; q += 2) {
+                load_c(cb, q + 1);
+                { const RowC& rr = ca; const f32x4 rb = rhbuf[(q / NP) * 64 + lane]; KWS_MMA_C(0); __builtin_amdgcn_sched_barrier(0); }
+                load_c(ca, q + 2);
+                { const RowC& rr = cb; const f32x4 rb = rhbuf[((q + 1) / NP) * 64 + lane];
+                  if (NP == 2) { KWS_MMA_C((NP - 1)); } else { KWS_MMA_C(0); } __builtin_amdgcn_sched_barrier(0); }
             }
+#undef KWS_MMA_C
         }
         const unsigned live = t < len_s ? 0xffffffffu : 0u;
         f32x4 accf = bfc4;
@@ -661,14 +699,23 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
             hbuf[n * 64 + lane] = hreg[j];
             if (!LAST) {
                 const f32x4 o = hreg[j];
-                p.h_out[((size_t)group * T + t) * NT * 64 + n * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+                float4* dst = p.h_out + ((size_t)group * T + t) * NT * 64 + n * 64 + lane;
+                if (PIPE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        __hip_atomic_store(reinterpret_cast<float*>(dst) + e, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    *dst = make_float4(o[0], o[1], o[2], o[3]);
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) accf = mfma4(p.wfc[(n * 4 + e) * 64 + lane], hout[e], accf);
             }
         }
         if (LAST && g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
-        __syncthreads();
+        __syncthreads();          // drains vmcnt(0): every wave's h_out rows of frame t have been written through
+        if (PIPE && !LAST && tid == 0)
+            __hip_atomic_store(p.ready_out + group, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (LAST) {
             if (w == (t & 3)) epilogue_fold(epi, t, lane);
             if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
@@ -685,6 +732,39 @@ __global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p)
     }
 }
 
+template <int TPW, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256) gru_layer_generic(const GruLayerParams p) {
+    gru_layer_generic_body<TPW, FIRST, LAST, false>(p, blockIdx.x);
+}
+
+// Layer-pipelined launch: ONE grid of L x G workgroups, layer-major, so that every layer of every 16-stream group
+// runs concurrently on its own CU and layer l consumes frame t of layer l-1 as soon as it is published (a per-group
+// frame counter in global memory: release after the h_out stores, acquire before the x loads).  Wall time becomes
+// (T + L - 1) frame times instead of L x T.  It pays when L x G workgroups fit the chip at once -- BASELINE
+// configs[4] (L = 4, B = 1024: 256 workgroups on 256 CUs) -- and cannot deadlock in any case: a workgroup only
+// waits for one with a smaller index, and workgroups are dispatched in index order.
+//
+// XCD affinity: workgroups are dealt round-robin to the 8 XCDs (block i -> XCD i % 8), each with its own 4 MB L2.
+// Layer-major order would put every layer's weight stream (1.5 MB per layer at H = 256, 6 MB in all) through every
+// L2; with L dividing 8 the mapping below gives XCD x the layer x % L only (measured at configs[4]: 9.32 vs 9.53 ms),
+// and a workgroup still waits only for block i - 1.
+template <int TPW>
+__global__ void __launch_bounds__(256) gru_stack_generic_pipelined(const GruStackParams sp) {
+    int layer, group;
+    if (sp.xcd_affine) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = 8 / sp.L;
+        layer = xcd % sp.L;
+        group = slot * per + xcd / sp.L;
+        if (group >= sp.G) return;              // grid padded to a multiple of 8; nobody waits for a padding block
+    } else {
+        layer = blockIdx.x / sp.G;
+        group = blockIdx.x - layer * sp.G;
+    }
+    if (layer == 0) gru_layer_generic_body<TPW, true, false, true>(sp.layer[0], group);
+    else if (layer == sp.L - 1) gru_layer_generic_body<TPW, false, true, true>(sp.layer[layer], group);
+    else gru_layer_generic_body<TPW, false, false, true>(sp.layer[layer], group);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -695,7 +775,7 @@ static size_t resident_lds_bytes(int kcx, bool first, bool last) {
     return n;
 }
 static size_t generic_lds_bytes(int hidden, bool last) {
-    size_t n = (size_t)2 * (hidden / 16) * 64 * 16;
+    size_t n = (size_t)3 * (hidden / 16) * 64 * 16 + (size_t)3 * hidden * 4;
     if (last) n += kEpilogueLdsBytes;
     return n;
 }
@@ -732,6 +812,29 @@ hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool l
     }
     if (last) KWS_RES(32, false, true); else KWS_RES(32, false, false);
 #undef KWS_RES
+}
+
+template <int TPW>
+static hipError_t launch_pipelined(const GruStackParams& sp, size_t lds, hipStream_t st) {
+    static size_t granted = 0;
+    if (lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_stack_generic_pipelined<TPW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted = lds;
+    }
+    const int per = sp.xcd_affine ? 8 / sp.L : 0;
+    const int grid = sp.xcd_affine ? 8 * ((sp.G + per - 1) / per) : sp.G * sp.L;
+    hipLaunchKernelGGL(gru_stack_generic_pipelined<TPW>, dim3(grid), dim3(256), lds, st, sp);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_stack_generic_pipelined(const GruStackParams& sp, int hidden, hipStream_t st) {
+    const size_t lds = generic_lds_bytes(hidden, true);
+    if (hidden == 64) return launch_pipelined<1>(sp, lds, st);
+    if (hidden == 128) return launch_pipelined<2>(sp, lds, st);
+    if (hidden == 256) return launch_pipelined<4>(sp, lds, st);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_gru_layer_generic(const GruLayerParams& p, int hidden, bool first, bool last,

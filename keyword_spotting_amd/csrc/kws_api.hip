@@ -63,7 +63,15 @@ struct kws_model {
     int32_t* oct_prev = nullptr;     // [B] copy of prev_word
     size_t oct_groups = 0;
     float* d_weights = nullptr;
-    float4* scratch[2] = {nullptr, nullptr};
+    float4* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // seam l = scratch[l % nscratch]
+    int nscratch = 0;
+    bool scratch_fine = false;
+    // layer-pipelined launch of the generic kernel
+    int num_cus = 0;
+    int* pipe_ready = nullptr;       // [L][groups] frames published
+    size_t pipe_groups = 0;
+    int* pipe_error_host = nullptr;  // mapped pinned flag the kernel raises if a wait times out
+    int* pipe_error_dev = nullptr;
     size_t scratch_bytes = 0;
     // profiling
     bool profiling = false;
@@ -201,6 +209,10 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
     if (!m) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
     m->cfg = *cfg;
     KWS_HIP(hipGetDevice(&m->device));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, m->device) == hipSuccess) m->num_cus = prop.multiProcessorCount;
+    }
     const int H = cfg->hidden, NT = H / 16, KCH = H / 4, C = cfg->num_classes;
 
     std::vector<float> host;
@@ -398,7 +410,9 @@ int kws_destroy(kws_handle h) {
     for (auto& pd : h->pending) { hipEventDestroy(pd.a); hipEventDestroy(pd.b); }
     for (auto ev : h->event_pool) hipEventDestroy(ev);
     if (h->d_weights) hipFree(h->d_weights);
-    for (int i = 0; i < 2; ++i) if (h->scratch[i]) hipFree(h->scratch[i]);
+    for (int i = 0; i < 8; ++i) if (h->scratch[i]) hipFree(h->scratch[i]);
+    if (h->pipe_ready) hipFree(h->pipe_ready);
+    if (h->pipe_error_host) hipHostFree(h->pipe_error_host);
     if (h->oct_aq) hipFree(h->oct_aq);
     if (h->oct_range) hipFree(h->oct_range);
     if (h->oct_prev) hipFree(h->oct_prev);
@@ -419,6 +433,16 @@ int kws_set_kernel(kws_handle h, int kind) {
     return KWS_OK;
 }
 
+// The layer-pipelined launch needs all L x groups workgroups resident at once (one per CU) and the streaming kernel
+// on every layer; it pays when the layers would otherwise leave CUs idle.
+static bool pipeline_eligible(kws_handle h, int B) {
+    if (h->cfg.precision != KWS_FP32 || h->cfg.num_layers < 2 || h->kernel_kind == KWS_KERNEL_RESIDENT) return false;
+    for (const auto& L : h->layers)
+        if (h->kernel_kind == KWS_KERNEL_AUTO && L.resident_ok) return false;
+    const long long groups = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
+    return h->num_cus > 0 && groups * h->cfg.num_layers <= h->num_cus;
+}
+
 static int ensure_scratch(kws_handle h, int B, int T) {
     const size_t groups = (size_t)(B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
     if (h->cfg.precision == KWS_INT8 && groups > h->oct_groups) {
@@ -434,12 +458,22 @@ static int ensure_scratch(kws_handle h, int B, int T) {
     }
     if (h->cfg.num_layers < 2 && h->cfg.precision != KWS_INT8) return KWS_OK;
     const size_t bytes = groups * (size_t)T * h->cfg.hidden * 16 * sizeof(float);
-    if (bytes <= h->scratch_bytes) return KWS_OK;
+    const int want_bufs = pipeline_eligible(h, B) ? h->cfg.num_layers - 1 : 0;
+    if (bytes <= h->scratch_bytes && want_bufs <= h->nscratch && (want_bufs == 0 || h->scratch_fine)) return KWS_OK;
     KWS_HIP(hipDeviceSynchronize());
-    for (int i = 0; i < 2; ++i) if (h->scratch[i]) { hipFree(h->scratch[i]); h->scratch[i] = nullptr; }
+    for (int i = 0; i < 8; ++i) if (h->scratch[i]) { hipFree(h->scratch[i]); h->scratch[i] = nullptr; }
     h->scratch_bytes = 0;
-    const int nbuf = (h->cfg.num_layers > 2 || h->cfg.precision == KWS_INT8) ? 2 : 1;
-    for (int i = 0; i < nbuf; ++i) KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
+    // sequential launches ping-pong two buffers; the layer-pipelined launch has every seam live at once
+    int nbuf = (h->cfg.num_layers > 2 || h->cfg.precision == KWS_INT8) ? 2 : 1;
+    const bool fine = pipeline_eligible(h, B);
+    if (fine) nbuf = h->cfg.num_layers - 1;
+    // pipelined seams are read by another XCD while the kernel runs: fine-grained (uncached, coherent) memory
+    for (int i = 0; i < nbuf; ++i) {
+        if (fine) KWS_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->scratch[i]), bytes, hipDeviceMallocFinegrained));
+        else KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
+    }
+    h->scratch_fine = fine;
+    h->nscratch = nbuf;
     h->scratch_bytes = bytes;
     return KWS_OK;
 }
@@ -535,6 +569,34 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     const bool int8 = c.precision == KWS_INT8;
     if (int8 && prev_word)
         KWS_HIP(hipMemcpyAsync(h->oct_prev, prev_word, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    // layer-pipelined launch (gru_stack_generic_pipelined): all layers of all groups in one grid
+    const bool pipelined = pipeline_eligible(h, B);
+    const int groups = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
+    kws::GruStackParams sp;
+    if (pipelined) {
+        if (h->pipe_error_host && *reinterpret_cast<volatile int*>(h->pipe_error_host)) {
+            *reinterpret_cast<volatile int*>(h->pipe_error_host) = 0;
+            return fail(KWS_ERR_HIP, "a layer-pipelined launch timed out waiting for the layer below; its results are invalid");
+        }
+        if (!h->pipe_error_host) {
+            KWS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pipe_error_host), sizeof(int), hipHostMallocMapped));
+            *h->pipe_error_host = 0;
+            KWS_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pipe_error_dev), h->pipe_error_host, 0));
+        }
+        if ((size_t)groups > h->pipe_groups) {
+            KWS_HIP(hipDeviceSynchronize());
+            if (h->pipe_ready) hipFree(h->pipe_ready);
+            h->pipe_ready = nullptr; h->pipe_groups = 0;
+            KWS_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->pipe_ready), (size_t)L * groups * sizeof(int), hipDeviceMallocFinegrained));
+            h->pipe_groups = groups;
+        }
+        KWS_HIP(hipMemsetAsync(h->pipe_ready, 0, (size_t)L * h->pipe_groups * sizeof(int), st));
+        memset(&sp, 0, sizeof(sp));
+        sp.L = L; sp.G = groups; sp.xcd_affine = (8 % L == 0) ? 1 : 0;
+#ifdef KWS_PIPE_NOAFFINITY
+        sp.xcd_affine = 0;
+#endif
+    }
     for (int l = 0; l < L; ++l) {
         const LayerDev& Ld = h->layers[l];
         // int8: every GRU layer hands its output rows to the next stage through the xl scratch; the class
@@ -552,8 +614,8 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         p.wfc = h->d_weights + h->wfc_off;
         p.bfc = h->d_weights + h->bfc_off;
         p.x_mel = mel;
-        p.x_prev = first ? nullptr : h->scratch[(l - 1) & 1];
-        p.h_out = last ? nullptr : h->scratch[l & 1];
+        p.x_prev = first ? nullptr : h->scratch[(l - 1) % h->nscratch];
+        p.h_out = last ? nullptr : h->scratch[l % h->nscratch];
         p.state_in = state_in + (size_t)l * B * H;
         p.state_out = state_out + (size_t)l * B * H;
         p.seq_len = seq_len;
@@ -574,6 +636,13 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         if (!dbg_buf[l]) hipMalloc(reinterpret_cast<void**>(&dbg_buf[l]), (size_t)4096 * 4 * 8 * 8 * 2);
         p.dbg = groups_ <= 4096 ? dbg_buf[l] : nullptr;
 #endif
+        if (pipelined) {
+            p.ready_in = first ? nullptr : h->pipe_ready + (size_t)(l - 1) * h->pipe_groups;
+            p.ready_out = last ? nullptr : h->pipe_ready + (size_t)l * h->pipe_groups;
+            p.pipe_error = h->pipe_error_dev;
+            sp.layer[l] = p;
+            if (!last) continue;
+        }
         hipEvent_t ea = nullptr, eb = nullptr;
         if (h->profiling) {
             for (hipEvent_t* ev : {&ea, &eb}) {
@@ -583,7 +652,10 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             KWS_HIP(hipEventRecord(ea, st));
         }
         hipError_t e;
-        if (int8 && h->oct[l].quantised) {
+        if (pipelined) {
+            e = kws::launch_gru_stack_generic_pipelined(sp, H, st);       // timed as the last layer's slot
+            if (e != hipSuccess) return hip_fail(e, "launch gru_stack_generic_pipelined");
+        } else if (int8 && h->oct[l].quantised) {
             const kws_model::OctLayer& O = h->oct[l];
             kws::GruOctbitParams op;
             memset(&op, 0, sizeof(op));
@@ -632,7 +704,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             fp.b127 = h->d_weights + h->oct_b127fc;
             fp.bfc = h->d_weights + h->bfc_off;
             fp.scale_w = h->oct_scale_fc;
-            fp.h_top = h->scratch[l & 1];
+            fp.h_top = h->scratch[l % h->nscratch];
             fp.range = h->oct_range;
             fp.prev_in = prev_word ? h->oct_prev : nullptr;
             fp.logits = logits; fp.softmax = softmax; fp.tokens = tokens; fp.prev_word = prev_word;

@@ -42,7 +42,17 @@ struct GruLayerParams {
     int B, T, I, C;
     int KCX;                // x-part k-chunks (generic: multiple of 4)
     unsigned long long* dbg;  // timing-variant builds only (tools/build_variant.sh -DKWS_TIMING)
+    // layer-pipelined launch (generic kernel): frames published by the layer below / by this layer, per group
+    const int* ready_in;
+    int* ready_out;
+    int* pipe_error;
 };
+struct GruStackParams {
+    GruLayerParams layer[8];
+    int L, G;
+    int xcd_affine;   // L divides 8: block i -> (layer = (i % 8) % L, group = (i / 8) * (8 / L) + (i % 8) / L)
+};
+hipError_t launch_gru_stack_generic_pipelined(const GruStackParams& sp, int hidden, hipStream_t st);
 
 // bf16 fused stack (gru_bf16.hip): every layer in one launch, no inter-layer scratch
 struct GruBf16Params {
