@@ -692,7 +692,9 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float c = tanh_f(acc_c[j][e]);
-                const float hn = u[j][e] * hreg[j][e] + (1.0f - u[j][e]) * c;
+                // explicit fma: which of the two products -ffp-contract fuses must not depend on the instantiation
+                // (sequential and pipelined launches have to agree bit for bit)
+                const float hn = fmaf(u[j][e], hreg[j][e], (1.0f - u[j][e]) * c);
                 hreg[j][e] = bitsel(live, hn, hreg[j][e]);
                 hout[e] = bitsel(live, hn, 0.f);
             }

@@ -104,3 +104,32 @@ def test_two_handles_on_two_streams_do_not_interfere():
     torch.cuda.synchronize()
     for x, y in zip(ref_a + ref_b + [sa, sb], got_a + got_b + [sta, stb]):
         assert torch.equal(x, y)
+
+
+def test_layer_pipelined_launch_equals_sequential_launches():
+    """The streaming kernel launches all layers in one grid when L x groups fits the CUs (producer/consumer per frame)
+    and layer by layer otherwise; both must give the same bits.  2080 streams x 2 layers = 260 workgroups does not
+    fit 256 CUs -> sequential; its first 300 streams alone (19 groups) -> pipelined."""
+    import torch
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    from oracle import gru_oracle as G
+    for layers, hidden, n_mel in ((2, 128, 40), (4, 256, 60), (3, 64, 40)):
+        cfg = get_config(num_layers=layers, hidden_size=hidden, n_mel=n_mel)
+        w = G.random_weights(n_mel, hidden, layers, 6, seed=411)
+        big = 16 * (256 // layers + 2)
+        mel = torch.from_numpy(G.synthetic_mel(big, 37, n_mel, seed=412)).cuda()
+        st = (0.3 * torch.randn(layers, big, hidden, generator=torch.Generator().manual_seed(5))).cuda()
+        m = DeployModel(cfg, w, kernel="generic")
+        seq = m.forward(mel, st)                                  # too many groups: one launch per layer
+        k = 300
+        pip = m.forward(mel[:k].contiguous(), st[:, :k].contiguous())     # fits: layer-pipelined
+        assert torch.equal(pip["logits"], seq["logits"][:k])
+        assert torch.equal(pip["state"], seq["state"][:, :k])
+        # chunked through the pipelined path == one shot
+        s2, parts, pos = st[:, :k].contiguous(), [], 0
+        for n in (1, 22, 14):
+            r = m.forward(mel[:k, pos:pos + n].contiguous(), s2)
+            s2, pos = r["state"], pos + n
+            parts.append(r["logits"])
+        assert torch.equal(torch.cat(parts, 1), pip["logits"]) and torch.equal(s2, pip["state"])
