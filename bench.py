@@ -42,6 +42,61 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
+def secondary_lines(device):
+    """Informational figures for the other BASELINE configs, measured after the timed region on rank 0 (never part of
+    `value`): the bf16 and int8 variants of the headline workload, the end-to-end PCM -> trigger streaming loop and
+    configs[4].  A few seconds in total."""
+    import torch
+    from keyword_spotting_amd import get_config, weights
+    from keyword_spotting_amd.detector import StreamManager
+    from keyword_spotting_amd.frontend import MelFrontend
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / n
+
+    out = {}
+    B, T = 4096, 300
+    for prec, steps in (("bf16", 5), ("int8", 3)):
+        cfg = get_config(precision=prec)
+        m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+        mel = (torch.randn(B, T, cfg.n_mel, device=device).abs() * 2).contiguous()
+        st, pw = m.zero_state(B), m.fresh_prev_word(B)
+        dt = timed(lambda: m.forward(mel, st, prev_word=pw, state_out=st), steps)
+        out["configs[2] %s, %d streams x %d frames" % (prec, B, T)] = {"mel_frames_per_s": B * T / dt, "ms_per_step": dt * 1e3}
+        m.close()
+    cfg = get_config()
+    m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+    fe, mgr = MelFrontend(cfg), StreamManager(m, B)
+    pcm = torch.randn(B, 3600 * 4, device=device) * 0.1
+    k = [0]
+    def chunk():
+        mgr.feed_pcm(pcm[:, 3600 * (k[0] % 4):3600 * (k[0] % 4 + 1)], fe)
+        k[0] += 1
+    for _ in range(3):
+        chunk()
+    dt = timed(chunk, 20)
+    out["detector.py loop, PCM in -> trigger out, fp32, %d streams x 225 ms chunks (VAD, front-end, GRU, window)" % B] = {
+        "realtime_streams": B * 0.225 / dt, "ms_per_chunk": dt * 1e3}
+    m.close()
+    cfg = get_config(n_mel=60, hidden_size=256, num_layers=4)
+    m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+    mel = (torch.randn(1024, T, 60, device=device).abs() * 2).contiguous()
+    st = m.zero_state(1024)
+    dt = timed(lambda: m.forward(mel, st, state_out=st), 3)
+    macs = sum(((60 if l == 0 else 256) + 256) * 3 * 256 for l in range(4)) + 256 * 6
+    out["configs[4] 4xGRU h=256 n_mel=60, 1024 streams x %d frames, fp32 (layer-pipelined launch)" % T] = {
+        "mel_frames_per_s": 1024 * T / dt, "ms_per_step": dt * 1e3, "tflops": 2 * macs * 1024 * T / dt / 1e12}
+    m.close()
+    return out
+
+
 def cpu_baseline(cfg, w, seconds_budget=10.0):
     """The oracle timed on this host (reference TF-1.x is not executable here or on the GPU box):
     (ii) tight C restatement, 1 core and all cores; (i) torch-CPU eager op-by-op = 'TF-CPU stand-in'.
@@ -242,6 +297,10 @@ def main():
                          "hbm_frac_of_peak": BYTES_PER_FRAME * B * T / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["secondary"] = secondary_lines(device)
+            except Exception as exc:          # informational only: never lose the headline line over it
+                line["secondary"] = {"error": repr(exc)}
             line["cpu_baseline"] = cpu_baseline(cfg, w)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
             line["speedup_vs_eager_stand_in_x_cores"] = value / (line["cpu_baseline"]["eager_stand_in"]["value"]
