@@ -665,8 +665,11 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
             rhbuf[(TPW * w + j) * 64 + lane] = rh;
         }
         RowC ca, cb;
+        if (PIPE && !LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last frame's rows (half a frame old): written through
         load_c(ca, 0);                 // does not depend on the exchange: issued ahead of the barrier
         __syncthreads();
+        if (PIPE && !LAST && t > 0 && tid == 0)
+            __hip_atomic_store(p.ready_out + group, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         {
 #define KWS_MMA_C(P_)                                                                                 \
             _Pragma("unroll") for (int j = 0; j < RT; ++j)                                             \
@@ -715,9 +718,11 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
             }
         }
         if (LAST && g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
-        __syncthreads();          // drains vmcnt(0): every wave's h_out rows of frame t have been written through
-        if (PIPE && !LAST && tid == 0)
-            __hip_atomic_store(p.ready_out + group, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        // Pipelined producer: the counter of frame t moves at the NEXT frame's mid barrier (below), after every wave has
+        // drained its stores there -- __syncthreads() itself does not wait for global stores (workgroup scope), and a
+        // consumer on another CU must not see the counter before the rows (found by tools/stress_determinism.py: only
+        // the first call after create showed it, later calls re-read the identical rows of the previous call).
         if (LAST) {
             if (w == (t & 3)) epilogue_fold(epi, t, lane);
             if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
@@ -726,6 +731,11 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
                 epilogue_flush(p, epi, group, t0, t - t0 + 1, w, lane, t == T - 1);
             }
         }
+    }
+    if (PIPE && !LAST) {                         // the last frame
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.ready_out + group, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (bvalid) {
 #pragma unroll

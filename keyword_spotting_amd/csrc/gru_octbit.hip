@@ -224,7 +224,11 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
         // ---- gates: quantise [x, h], exchange, dot, finalize ----------------------------------------
         quantise(0);
         OCT_TS(0);
-        __syncthreads();                                   // stores complete (vmcnt 0) and visible in L2
+        // __syncthreads() alone does NOT wait for global stores (workgroup scope only orders them inside the CU's L1);
+        // the scalar loads below go through the scalar cache to L2, so the stores must have been acknowledged by L2
+        // first.  (Without the explicit vmcnt(0): rare stale rows, found by tools/stress_determinism.py.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         scalar_cache_invalidate();
         OCT_TS(1);
         {
@@ -273,9 +277,10 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
         OCT_TS(5);
         // ---- candidate: quantise [x, r (.) h], exchange, dot, finalize + state update ---------------
         quantise(1);
-        if (t + 1 < T) load_x(t + 1);                      // x of this frame is consumed
         OCT_TS(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // exchange rows in L2 before any wave's scalar loads
         __syncthreads();
+        if (t + 1 < T) load_x(t + 1);                      // x of this frame is consumed; issued after the drain so it stays in flight
         scalar_cache_invalidate();
         OCT_TS(7);
         {

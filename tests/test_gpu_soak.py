@@ -133,3 +133,32 @@ def test_layer_pipelined_launch_equals_sequential_launches():
             s2, pos = r["state"], pos + n
             parts.append(r["logits"])
         assert torch.equal(torch.cat(parts, 1), pip["logits"]) and torch.equal(s2, pip["state"])
+
+
+def test_no_stale_data_leaks_between_calls():
+    """Paths that hand data between CUs inside one kernel (int8: vector stores -> scalar loads; layer-pipelined launch:
+    producer -> consumer workgroups) once raced in a way that repeating identical calls cannot see: a stale read returns
+    the previous call's identical bytes.  So: a call on DIFFERENT inputs must equal a fresh model's first call."""
+    import torch
+    from keyword_spotting_amd import get_config, weights
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cases = [("int8", get_config(precision="int8"), 4096, 24, "auto"),
+             ("pipelined 4x256", get_config(n_mel=60, hidden_size=256, num_layers=4), 1024, 24, "auto"),
+             ("pipelined 8x64", get_config(hidden_size=64, num_layers=8), 512, 24, "auto"),
+             ("bf16", get_config(precision="bf16"), 4096, 24, "auto"),
+             ("fp32 resident", get_config(), 4096, 24, "auto")]
+    g = torch.Generator(device="cuda").manual_seed(77)
+    for name, cfg, b, t, kernel in cases:
+        w = weights.init_weights(cfg, seed=9)
+        x1 = (torch.randn(b, t, cfg.n_mel, device="cuda", generator=g).abs() * 2).contiguous()
+        x2 = (torch.randn(b, t, cfg.n_mel, device="cuda", generator=g).abs() * 2).contiguous()
+        s1 = (0.3 * torch.randn(cfg.num_layers, b, cfg.hidden_size, device="cuda", generator=g)).contiguous()
+        s2 = (0.3 * torch.randn(cfg.num_layers, b, cfg.hidden_size, device="cuda", generator=g)).contiguous()
+        m = DeployModel(cfg, w, kernel=kernel)
+        first = m.forward(x1, s1)
+        again = [m.forward(x2, s2) for _ in range(3)]
+        fresh = DeployModel(cfg, w, kernel=kernel).forward(x2, s2)
+        back = m.forward(x1, s1)
+        for r in again:
+            assert torch.equal(r["logits"], fresh["logits"]) and torch.equal(r["state"], fresh["state"]), name
+        assert torch.equal(back["logits"], first["logits"]) and torch.equal(back["state"], first["state"]), name
