@@ -436,6 +436,9 @@ int kws_set_kernel(kws_handle h, int kind) {
 // The layer-pipelined launch needs all L x groups workgroups resident at once (one per CU) and the streaming kernel
 // on every layer; it pays when the layers would otherwise leave CUs idle.
 static bool pipeline_eligible(kws_handle h, int B) {
+    // AUTO keeps the resident kernels where they exist even when this launch would be faster (H=128, L=2: +10 % at
+    // B <= 2048; L=4, B=1024: 2.2x; select it with KWS_KERNEL_GENERIC): the two kernel families round differently in
+    // the last bit, and a stream's result must not depend on how many neighbours it is batched or sharded with.
     if (h->cfg.precision != KWS_FP32 || h->cfg.num_layers < 2 || h->kernel_kind == KWS_KERNEL_RESIDENT) return false;
     for (const auto& L : h->layers)
         if (h->kernel_kind == KWS_KERNEL_AUTO && L.resident_ok) return false;
@@ -602,8 +605,8 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         // int8: every GRU layer hands its output rows to the next stage through the xl scratch; the class
         // projection is its own OctbitMatMul call over the whole [T,H] block (launch_octbit_fc below)
         const bool first = l == 0, last = !int8 && l == L - 1;
-        const bool resident = h->kernel_kind == KWS_KERNEL_RESIDENT ||
-                              (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok);
+        const bool resident = !pipelined && (h->kernel_kind == KWS_KERNEL_RESIDENT ||
+                                             (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok));
         kws::GruLayerParams p;
         memset(&p, 0, sizeof(p));
         // resident kernels read the group-of-4 layouts too (dwordx4 prologue), except the first layer's
