@@ -113,6 +113,24 @@ __device__ __forceinline__ uint32_t quant_u8(float v, float bscale, float off) {
     return bscale == 0.f ? 0u : (uint32_t)(int)(r + off) & 0xffu;
 }
 
+// min / max over the 32-lane half a stream's row is spread over, without LDS traffic: four DPP rotations inside each
+// row of 16, then gfx950's v_permlane16_swap pairs row 0 with row 1 (and 2 with 3).  (__shfl_xor compiles to
+// ds_bpermute: ten LDS round trips per range.)
+template <bool MAX>
+__device__ __forceinline__ float half_wave_reduce(float v) {
+#define KWS_ROR(ctrl_)                                                                                     \
+    {                                                                                                      \
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl_, 0xf, 0xf, false)); \
+        v = MAX ? fmaxf(v, o) : fminf(v, o);                                                               \
+    }
+    KWS_ROR(0x128) KWS_ROR(0x124) KWS_ROR(0x122) KWS_ROR(0x121)
+#undef KWS_ROR
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float a = __uint_as_float(sw[0]), b = __uint_as_float(sw[1]);
+    return MAX ? fmaxf(a, b) : fminf(a, b);
+}
+
 // range of the call (:92-99) -> (bscale, signed); an all-zero call has bscale 0 (output defined as 0)
 __device__ __forceinline__ void range_to_scale(float mn, float mx, float& bscale, int& is_signed) {
     is_signed = mn < 0.f;
@@ -182,11 +200,8 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
         }
         float mn = fminf(fminf(fminf(va[0], va[1]), fminf(va[2], va[3])), fminf(fminf(vb[0], vb[1]), fminf(vb[2], vb[3])));
         float mx = fmaxf(fmaxf(fmaxf(va[0], va[1]), fmaxf(va[2], va[3])), fmaxf(fmaxf(vb[0], vb[1]), fmaxf(vb[2], vb[3])));
-#pragma unroll
-        for (int m = 16; m > 0; m >>= 1) {
-            mn = fminf(mn, __shfl_xor(mn, m, 32));
-            mx = fmaxf(mx, __shfl_xor(mx, m, 32));
-        }
+        mn = half_wave_reduce<false>(mn);
+        mx = half_wave_reduce<true>(mx);
         float bscale;
         int is_signed;
         range_to_scale(mn, mx, bscale, is_signed);
