@@ -74,10 +74,10 @@ def secondary_lines(device):
     cfg = get_config()
     m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
     fe, mgr = MelFrontend(cfg), StreamManager(m, B)
-    pcm = torch.randn(B, 3600 * 4, device=device) * 0.1
+    pcm = [(torch.randn(B, 3600, device=device) * 0.1).contiguous() for _ in range(4)]
     k = [0]
     def chunk():
-        mgr.feed_pcm(pcm[:, 3600 * (k[0] % 4):3600 * (k[0] % 4 + 1)], fe)
+        mgr.feed_pcm(pcm[k[0] % 4], fe)
         k[0] += 1
     for _ in range(3):
         chunk()
