@@ -104,3 +104,16 @@ def test_tf_variable_names_round_trip(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "convert_weights.py"), str(src), "--out",
                            str(tmp_path / "m")])
     np.testing.assert_array_equal(np.fromfile(tmp_path / "m.blob", np.float32), weights.to_blob(cfg, w))
+
+
+def test_buf_to_float_matches_the_ring_buffer_conversion():
+    """detector.py:40-43: scale = 1 / 2^(8n-1) applied to little-endian signed PCM (RingBuffer.get, :74-79)."""
+    import torch
+    from keyword_spotting_amd.detector import buf_to_float
+    raw = np.array([-32768, -1, 0, 1, 12345, 32767], np.int16)
+    want = (1.0 / float(1 << 15)) * raw.astype(np.float32)              # the reference's expression
+    np.testing.assert_array_equal(buf_to_float(torch.from_numpy(raw)).numpy(), want)
+    f = torch.tensor([0.25, -0.5])
+    assert buf_to_float(f) is f or torch.equal(buf_to_float(f), f)      # float input passes through
+    with pytest.raises(ValueError):
+        buf_to_float(torch.zeros(3, dtype=torch.int64))
