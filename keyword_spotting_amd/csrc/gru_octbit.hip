@@ -223,6 +223,11 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
         *reinterpret_cast<f32x4*>(p.h_out + (((size_t)G * T + t) * 8 + (n4 >> 2)) * 64 + 16 * (n4 & 3) + ss) = v;
     };
 
+    // range of the emitted rows per stream (the class projection's activation range, :92-99), tracked where h' is made
+    float rmin[4], rmax[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { rmin[j] = 3.402823466e+38f; rmax[j] = -3.402823466e+38f; }
+
     load_x(0);
     __syncthreads();
 #ifdef KWS_TIMING
@@ -342,7 +347,11 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
             const float cand = tanh_f(add_rn(mul_rn(of, sc), bcB));
             const float u = ub[s * kHS + nB], hp = hs[s * kHS + nB];
             const float hn = add_rn(mul_rn(u, hp), mul_rn(sub_rn(1.0f, u), cand));
-            if (t < slen[s]) hs[s * kHS + nB] = hn;
+            if (t < slen[s]) {
+                hs[s * kHS + nB] = hn;
+                rmin[j] = fminf(rmin[j], hn);
+                rmax[j] = fmaxf(rmax[j], hn);
+            }
         }
         OCT_TS(10);
         lds_barrier();
@@ -357,6 +366,24 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
         const int s = i >> 7, n = i & 127;
         const int b = G * 16 + s;
         if (b < p.B) p.state_out[(size_t)b * 128 + n] = hs[s * kHS + n];
+    }
+    if (p.range) {
+        // fold over the 128 units of each stream: stream sB0 + j is owned by the 128 threads with the same tid >> 7
+        float* red = reinterpret_cast<float*>(part);            // [16 streams][128][2]
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[((sB0 + j) * 128 + nB) * 2 + 0] = rmin[j];
+            red[((sB0 + j) * 128 + nB) * 2 + 1] = rmax[j];
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+            for (int n = 0; n < 128; ++n) { mn = fminf(mn, red[(tid * 128 + n) * 2]); mx = fmaxf(mx, red[(tid * 128 + n) * 2 + 1]); }
+            if (slen[tid] < T) { mn = fminf(mn, 0.f); mx = fmaxf(mx, 0.f); }      // finished frames emit the zero row
+            if (slen[tid] <= 0 && T > 0) { mn = 0.f; mx = 0.f; }
+            p.range[G * 16 + tid] = make_float2(mn, mx);
+        }
     }
 }
 
@@ -502,7 +529,8 @@ hipError_t launch_gru_layer_octbit(const GruOctbitParams& p, hipStream_t st) {
 
 hipError_t launch_octbit_fc(const OctbitFcParams& p, hipStream_t st) {
     const int groups = (p.B + 15) / 16;
-    hipLaunchKernelGGL(octbit_top_range_kernel, dim3(groups), dim3(512), 0, st, p.h_top, p.T, p.range);
+    if (!p.range_ready)          // top layer ran on the fp32 kernels (one-layer models): scan its rows
+        hipLaunchKernelGGL(octbit_top_range_kernel, dim3(groups), dim3(512), 0, st, p.h_top, p.T, p.range);
     hipLaunchKernelGGL(octbit_fc_kernel, dim3(groups, (p.T + kFcFrames - 1) / kFcFrames), dim3(512), 0, st, p);
     return hipGetLastError();
 }

@@ -670,6 +670,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             op.state_in = p.state_in; op.state_out = p.state_out;
             op.seq_len = seq_len; op.reset = reset_mask;
             op.aq = h->oct_aq; op.B = B; op.T = T;
+            op.range = (l == L - 1) ? h->oct_range : nullptr;
 #ifdef KWS_TIMING
             static unsigned long long* odbg = nullptr;
             if (!odbg) hipMalloc(reinterpret_cast<void**>(&odbg), (size_t)4096 * 8 * 12 * 8);
@@ -709,6 +710,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             fp.scale_w = h->oct_scale_fc;
             fp.h_top = h->scratch[l % h->nscratch];
             fp.range = h->oct_range;
+            fp.range_ready = h->oct[l].quantised ? 1 : 0;
             fp.prev_in = prev_word ? h->oct_prev : nullptr;
             fp.logits = logits; fp.softmax = softmax; fp.tokens = tokens; fp.prev_word = prev_word;
             fp.decode_thres = decode2_thres; fp.value_clip = c.value_clip; fp.use_relu = c.use_relu;

@@ -85,6 +85,7 @@ struct GruOctbitParams {
     const int32_t* seq_len;
     const uint8_t* reset;
     uint32_t* aq;           // activation exchange [G][2][16 streams][128 dwords]
+    float2* range;          // top layer only: (min, max) of each stream's emitted rows, for the projection; else null
     int B, T;
     unsigned long long* dbg;  // timing-variant builds only (-DKWS_TIMING)
 };
@@ -95,6 +96,7 @@ struct OctbitFcParams {
     float scale_w;
     const float4* h_top;    // top layer output, xl layout
     float2* range;          // [G*16] (min, max) of each stream's [T,H] block
+    int range_ready;        // the top int8 layer already produced it
     const int32_t* prev_in; // copy of prev_word taken before the launch (or null)
     float* logits; float* softmax; int8_t* tokens; int32_t* prev_word;
     float decode_thres, value_clip;
