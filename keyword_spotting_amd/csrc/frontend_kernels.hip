@@ -24,7 +24,10 @@
 
 namespace kws {
 
-constexpr int kFT = 4;      // frame tiles (of 16) per workgroup
+#ifndef KWS_FE_FT
+#define KWS_FE_FT 4
+#endif
+constexpr int kFT = KWS_FE_FT;      // frame tiles (of 16) per workgroup
 #ifndef KWS_FE_SF
 #define KWS_FE_SF 4
 #endif
@@ -155,7 +158,9 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
 #ifndef KWS_FE_NODFT
     fetch(a0, 0);
 #pragma unroll
-    for (int j = 0; j < UPW; ++j) asm volatile("s_nop 3" : "+a"(acc[j][0]), "+a"(acc[j][1]), "+a"(acc[j][2]), "+a"(acc[j][3]));
+    for (int j = 0; j < UPW; ++j)
+#pragma unroll
+        for (int ft = 0; ft < kFT; ++ft) asm volatile("s_nop 1" : "+a"(acc[j][ft]));
     int k4 = 0;
     for (; k4 + 1 < KC4; k4 += 2) {
         fetch(a1, k4 + 1);
@@ -166,7 +171,9 @@ __global__ void __launch_bounds__(256) mel_frontend_kernel(const FrontendParams 
     if (k4 < KC4) contract(a0, k4);
 #endif
 #pragma unroll
-    for (int j = 0; j < UPW; ++j) asm volatile("s_nop 15" : "+a"(acc[j][0]), "+a"(acc[j][1]), "+a"(acc[j][2]), "+a"(acc[j][3]));
+    for (int j = 0; j < UPW; ++j)
+#pragma unroll
+        for (int ft = 0; ft < kFT; ++ft) asm volatile("s_nop 15" : "+a"(acc[j][ft]));
     __syncthreads();                       // every wave is done with the windows: the partial sums reuse their space
 #pragma unroll
     for (int j = 0; j < UPW; ++j)
