@@ -66,6 +66,7 @@ struct kws_model {
     float4* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // seam l = scratch[l % nscratch]
     int nscratch = 0;
     bool scratch_fine = false;
+    bool pipe_disabled = false;      // fine-grained memory unavailable, or a pipelined launch timed out: sequential launches from then on
     // layer-pipelined launch of the generic kernel
     int num_cus = 0;
     int* pipe_ready = nullptr;       // [L][groups] frames published
@@ -439,6 +440,7 @@ static bool pipeline_eligible(kws_handle h, int B) {
     // AUTO keeps the resident kernels where they exist even when this launch would be faster (H=128, L=2: +10 % at
     // B <= 2048; L=4, B=1024: 2.2x; select it with KWS_KERNEL_GENERIC): the two kernel families round differently in
     // the last bit, and a stream's result must not depend on how many neighbours it is batched or sharded with.
+    if (h->pipe_disabled) return false;
     if (h->cfg.precision != KWS_FP32 || h->cfg.num_layers < 2 || h->kernel_kind == KWS_KERNEL_RESIDENT) return false;
     for (const auto& L : h->layers)
         if (h->kernel_kind == KWS_KERNEL_AUTO && L.resident_ok) return false;
@@ -472,8 +474,17 @@ static int ensure_scratch(kws_handle h, int B, int T) {
     if (fine) nbuf = h->cfg.num_layers - 1;
     // pipelined seams are read by another XCD while the kernel runs: fine-grained (uncached, coherent) memory
     for (int i = 0; i < nbuf; ++i) {
-        if (fine) KWS_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->scratch[i]), bytes, hipDeviceMallocFinegrained));
-        else KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
+        if (fine) {
+            if (hipExtMallocWithFlags(reinterpret_cast<void**>(&h->scratch[i]), bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                // no fine-grained device memory on this system: give the pipelined launch up for this handle
+                (void)hipGetLastError();
+                for (int k = 0; k < i; ++k) { hipFree(h->scratch[k]); h->scratch[k] = nullptr; }
+                h->pipe_disabled = true;
+                return ensure_scratch(h, B, T);
+            }
+        } else {
+            KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
+        }
     }
     h->scratch_fine = fine;
     h->nscratch = nbuf;
@@ -579,7 +590,8 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     if (pipelined) {
         if (h->pipe_error_host && *reinterpret_cast<volatile int*>(h->pipe_error_host)) {
             *reinterpret_cast<volatile int*>(h->pipe_error_host) = 0;
-            return fail(KWS_ERR_HIP, "a layer-pipelined launch timed out waiting for the layer below; its results are invalid");
+            h->pipe_disabled = true;             // later steps launch layer by layer
+            return fail(KWS_ERR_HIP, "a layer-pipelined launch timed out waiting for the layer below; the previous step's results are invalid");
         }
         if (!h->pipe_error_host) {
             KWS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pipe_error_host), sizeof(int), hipHostMallocMapped));
@@ -590,7 +602,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             KWS_HIP(hipDeviceSynchronize());
             if (h->pipe_ready) hipFree(h->pipe_ready);
             h->pipe_ready = nullptr; h->pipe_groups = 0;
-            KWS_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->pipe_ready), (size_t)L * groups * sizeof(int), hipDeviceMallocFinegrained));
+            KWS_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->pipe_ready), (size_t)L * groups * sizeof(int), hipDeviceMallocFinegrained));   // seams were allocated the same way a moment ago
             h->pipe_groups = groups;
         }
         KWS_HIP(hipMemsetAsync(h->pipe_ready, 0, (size_t)L * h->pipe_groups * sizeof(int), st));
