@@ -238,7 +238,7 @@ __device__ __forceinline__ void epilogue_flush(const GruLayerParams& p, const Ep
     if (!(best > p.decode_thres)) word = -1;
     e.words[f * 16 + s] = word;
     const bool mine = b < p.B && f < n;
-    const size_t row = (size_t)b * p.T + (t0 + f);
+    const size_t row = (size_t)b * (p.t_stride ? p.t_stride : p.T) + (t0 + f);
     if (mine) {
         if (C == 6) {       // rows are 24 B: three 8-byte stores
             if (p.logits) {

@@ -136,7 +136,7 @@ gru_layer_resident(const GruLayerParams p) {
 
     // ---- initial state ---------------------------------------------------------------------------
     const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
-    const int len_s = p.seq_len ? p.seq_len[b] : T;
+    const int len_s = p.seq_len ? p.seq_len[b] - p.t_base : T;
     f32x4 hreg[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -163,7 +163,7 @@ gru_layer_resident(const GruLayerParams p) {
     const int xl_row = lane / XQ, xl_q = lane % XQ;  // this lane's (stream-in-quarter, piece)
     const bool xl_active = FIRST && lane < 4 * XQ;
     const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
-    const float4* xl_src = FIRST ? reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * T * p.I) + xl_q : nullptr;
+    const float4* xl_src = FIRST ? reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * (p.t_stride ? p.t_stride : T) * p.I) + xl_q : nullptr;
     float4 xl_inflight = make_float4(0.f, 0.f, 0.f, 0.f);
     auto coop_issue = [&](int t_req) {               // global -> register (in flight)
         const int t = t_req < T ? t_req : T - 1;
@@ -495,7 +495,7 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
     // they would pin are the difference between fitting the 512-register file and spilling
     f32x4 hreg[TPW];
     const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
-    const int len_s = p.seq_len ? p.seq_len[b] : T;
+    const int len_s = p.seq_len ? p.seq_len[b] - p.t_base : T;
     for (int i = tid; i < 3 * NT * 4; i += 256) biasl[i] = ld4(p.bias + 4 * i);   // [gate][tile][g] = bias[gate*H + 16*tile + 4g ..]
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
@@ -513,7 +513,7 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
             epi.carry[tid] = pw;
         }
     }
-    const float* xrow = FIRST ? p.x_mel + (size_t)b * T * I : nullptr;
+    const float* xrow = FIRST ? p.x_mel + (size_t)b * (p.t_stride ? p.t_stride : T) * I : nullptr;
     const f32x4* xprev = FIRST ? nullptr
                                : reinterpret_cast<const f32x4*>(p.x_prev) + (size_t)group * T * NT * 64 + lane;
     const bool vec_ok = (I & 3) == 0;

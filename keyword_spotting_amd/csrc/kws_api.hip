@@ -66,7 +66,10 @@ struct kws_model {
     float4* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // seam l = scratch[l % nscratch]
     int nscratch = 0;
     bool scratch_fine = false;
-    bool pipe_disabled = false;      // fine-grained memory unavailable, or a pipelined launch timed out: sequential launches from then on
+    bool pipe_disabled = false;
+    // time-blocked overlap of the layers on separate HIP streams (step_overlapped)
+    hipStream_t lane_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ovl_events;      // fine-grained memory unavailable, or a pipelined launch timed out: sequential launches from then on
     // layer-pipelined launch of the generic kernel
     int num_cus = 0;
     int* pipe_ready = nullptr;       // [L][groups] frames published
@@ -414,6 +417,8 @@ int kws_destroy(kws_handle h) {
     for (int i = 0; i < 8; ++i) if (h->scratch[i]) hipFree(h->scratch[i]);
     if (h->pipe_ready) hipFree(h->pipe_ready);
     if (h->pipe_error_host) hipHostFree(h->pipe_error_host);
+    for (auto ev : h->ovl_events) hipEventDestroy(ev);
+    for (auto sx : h->lane_stream) if (sx) hipStreamDestroy(sx);
     if (h->oct_aq) hipFree(h->oct_aq);
     if (h->oct_range) hipFree(h->oct_range);
     if (h->oct_prev) hipFree(h->oct_prev);
@@ -527,6 +532,91 @@ int kws_kernel_times(kws_handle h, float* ms_sum, int32_t* launches, int reset) 
     return KWS_OK;
 }
 
+// Layers on separate HIP streams, time-blocked.  When L x groups workgroups fit the chip at once, the layers of a
+// long call need not run one after another: the call is cut into time blocks, layer l works on block k while layer
+// l-1 already works on block k+1 (its own stream, ordered by events; seam buffers double-buffered per block parity).
+// The kernels are the ones a plain call uses -- a call on frames [t0, t1) with the state carried is bit-identical to
+// the corresponding slice of one long call (tests/test_gpu_parity.py) -- so the result does not depend on whether
+// this path was taken.  Wall time ~ (slowest layer) x (1 + 1/blocks) instead of the sum over layers.
+static bool overlap_eligible(kws_handle h, int B, int T) {
+    const kws_config& c = h->cfg;
+    if (c.precision != KWS_FP32 || c.num_layers < 2 || c.num_layers > 5 || h->profiling) return false;
+    if (pipeline_eligible(h, B)) return false;            // the streaming kernel has its own in-kernel pipeline
+    const long long groups = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
+    return h->num_cus > 0 && groups * c.num_layers <= h->num_cus && T >= 64;
+}
+
+static int step_overlapped(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
+                           float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
+                           int32_t* prev_word, float decode2_thres, int B, int T, hipStream_t st) {
+    const kws_config& c = h->cfg;
+    const int H = c.hidden, L = c.num_layers, C = c.num_classes;
+    int nb = T / 32 < 8 ? T / 32 : 8;              // more blocks: less fill/drain, more launch prologues (8: +6 % over 4)
+    const int Tb = ((T + nb - 1) / nb + 15) & ~15;        // multiple of the epilogue ring
+    nb = (T + Tb - 1) / Tb;
+    const size_t groups = (size_t)(B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
+    const size_t bytes = groups * (size_t)Tb * H * 16 * sizeof(float);
+    const int nbuf = 2 * (L - 1);
+    if (bytes > h->scratch_bytes || h->nscratch < nbuf || h->scratch_fine) {
+        KWS_HIP(hipDeviceSynchronize());
+        for (int i = 0; i < 8; ++i) if (h->scratch[i]) { hipFree(h->scratch[i]); h->scratch[i] = nullptr; }
+        h->scratch_bytes = 0; h->nscratch = 0; h->scratch_fine = false;
+        for (int i = 0; i < nbuf; ++i) KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
+        h->nscratch = nbuf; h->scratch_bytes = bytes;
+    }
+    for (int l = 1; l < L; ++l)
+        if (!h->lane_stream[l]) KWS_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+    while ((int)h->ovl_events.size() < L * nb + 1) {
+        hipEvent_t ev;
+        KWS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        h->ovl_events.push_back(ev);
+    }
+    auto done = [&](int l, int k) { return h->ovl_events[1 + l * nb + k]; };
+    KWS_HIP(hipEventRecord(h->ovl_events[0], st));                          // everything queued before this call
+    for (int l = 1; l < L; ++l) KWS_HIP(hipStreamWaitEvent(h->lane_stream[l], h->ovl_events[0], 0));
+    for (int k = 0; k < nb; ++k) {
+        const int t0 = k * Tb, tk = (T - t0 < Tb) ? T - t0 : Tb;
+        for (int l = 0; l < L; ++l) {
+            const LayerDev& Ld = h->layers[l];
+            const bool first = l == 0, last = l == L - 1;
+            const bool resident = h->kernel_kind == KWS_KERNEL_RESIDENT || (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok);
+            hipStream_t sx = first ? st : h->lane_stream[l];
+            if (!first) KWS_HIP(hipStreamWaitEvent(sx, done(l - 1, k), 0));                    // its input block
+            if (!last && k >= 2) KWS_HIP(hipStreamWaitEvent(sx, done(l + 1, k - 2), 0));       // its output buffer is free again
+            kws::GruLayerParams p;
+            memset(&p, 0, sizeof(p));
+            p.wx = h->d_weights + ((resident && first) ? Ld.wx_res : Ld.wx_gen);
+            p.wh = h->d_weights + Ld.wh_gen;
+            p.bias = h->d_weights + Ld.bias;
+            p.wfc = h->d_weights + h->wfc_off;
+            p.bfc = h->d_weights + h->bfc_off;
+            p.x_mel = mel + (size_t)t0 * c.n_mel;
+            p.x_prev = first ? nullptr : h->scratch[2 * (l - 1) + (k & 1)];
+            p.h_out = last ? nullptr : h->scratch[2 * l + (k & 1)];
+            p.state_in = (k == 0 ? state_in : state_out) + (size_t)l * B * H;
+            p.state_out = state_out + (size_t)l * B * H;
+            p.seq_len = seq_len;
+            p.reset = k == 0 ? reset_mask : nullptr;
+            p.logits = logits ? logits + (size_t)t0 * C : nullptr;
+            p.softmax = softmax ? softmax + (size_t)t0 * C : nullptr;
+            p.tokens = tokens ? tokens + t0 : nullptr;
+            p.prev_word = prev_word;
+            p.decode_thres = decode2_thres;
+            p.value_clip = c.value_clip;
+            p.use_relu = c.use_relu;
+            p.B = B; p.T = tk; p.I = Ld.in_dim; p.C = C;
+            p.t_stride = T; p.t_base = t0;
+            p.KCX = resident ? Ld.kcx_res : Ld.kcx_gen;
+            hipError_t e = resident ? kws::launch_gru_layer_resident(p, first, last, sx)
+                                    : kws::launch_gru_layer_generic(p, H, first, last, sx);
+            if (e != hipSuccess) return hip_fail(e, "launch (overlapped layers)");
+            KWS_HIP(hipEventRecord(done(l, k), sx));
+        }
+    }
+    for (int l = 1; l < L; ++l) KWS_HIP(hipStreamWaitEvent(st, done(l, nb - 1), 0));           // rejoin the caller's stream
+    return KWS_OK;
+}
+
 int kws_step(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
              float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
              int32_t* prev_word, float decode2_thres, int B, int T, void* stream) {
@@ -577,6 +667,9 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         return KWS_OK;
     }
     if ((reinterpret_cast<uintptr_t>(mel) & 15) != 0) return fail(KWS_ERR_INVALID_ARGUMENT, "mel must be 16-byte aligned");
+    if (overlap_eligible(h, B, T))
+        return step_overlapped(h, mel, state_in, logits, softmax, state_out, seq_len, reset_mask, tokens, prev_word,
+                               decode2_thres, B, T, st);
     int rc = ensure_scratch(h, B, T);
     if (rc != KWS_OK) return rc;
 

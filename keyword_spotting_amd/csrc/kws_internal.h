@@ -40,6 +40,8 @@ struct GruLayerParams {
     float value_clip;
     int use_relu;
     int B, T, I, C;
+    int t_stride;           // frames per stream row of x_mel / logits / softmax / tokens (0: T) -- a call on a time block
+    int t_base;             // of a longer sequence passes pre-offset pointers, the full row stride, and its first frame
     int KCX;                // x-part k-chunks (generic: multiple of 4)
     unsigned long long* dbg;  // timing-variant builds only (tools/build_variant.sh -DKWS_TIMING)
     // layer-pipelined launch (generic kernel): frames published by the layer below / by this layer, per group

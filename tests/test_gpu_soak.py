@@ -146,7 +146,8 @@ def test_no_stale_data_leaks_between_calls():
              ("pipelined 4x256", get_config(n_mel=60, hidden_size=256, num_layers=4), 1024, 24, "auto"),
              ("pipelined 8x64", get_config(hidden_size=64, num_layers=8), 512, 24, "auto"),
              ("bf16", get_config(precision="bf16"), 4096, 24, "auto"),
-             ("fp32 resident", get_config(), 4096, 24, "auto")]
+             ("fp32 resident", get_config(), 4096, 24, "auto"),
+             ("fp32 resident, layers overlapped on streams", get_config(), 1024, 96, "auto")]
     g = torch.Generator(device="cuda").manual_seed(77)
     for name, cfg, b, t, kernel in cases:
         w = weights.init_weights(cfg, seed=9)
@@ -162,3 +163,32 @@ def test_no_stale_data_leaks_between_calls():
         for r in again:
             assert torch.equal(r["logits"], fresh["logits"]) and torch.equal(r["state"], fresh["state"]), name
         assert torch.equal(back["logits"], first["logits"]) and torch.equal(back["state"], first["state"]), name
+
+
+def test_layers_overlapped_on_streams_equal_sequential_launches():
+    """Long calls on few streams run their layers on separate HIP streams, time-blocked (step_overlapped); long calls on
+    many streams run layer after layer.  Same kernels, so the same bits -- including fused tokens, prev_word carry,
+    sequence lengths that end inside a block, the reset mask and a frame count that is not a multiple of the block."""
+    import torch
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    from oracle import gru_oracle as G
+    for layers in (2, 3):
+        cfg = get_config(num_layers=layers)
+        w = G.random_weights(40, 128, layers, 6, seed=421)
+        w["Wfc"] = (w["Wfc"] * 3).astype(np.float32)
+        big, k, t = 16 * (256 // layers + 1), 200, 173
+        gen = torch.Generator().manual_seed(422)
+        mel = (torch.randn(big, t, 40, generator=gen).abs() * 2).cuda()
+        st = (0.3 * torch.randn(layers, big, 128, generator=gen)).cuda()
+        seq = torch.randint(0, t + 1, (big,), generator=gen).to(torch.int32)
+        seq[:3] = torch.tensor([0, t, 95])
+        rst = (torch.rand(big, generator=gen) < 0.3).to(torch.uint8)
+        m = DeployModel(cfg, w)
+        pw_a, pw_b = m.fresh_prev_word(big), m.fresh_prev_word(k)
+        a = m.forward(mel, st, seq_len=seq, reset_mask=rst, prev_word=pw_a)                       # sequential
+        b = m.forward(mel[:k].contiguous(), st[:, :k].contiguous(), seq_len=seq[:k], reset_mask=rst[:k], prev_word=pw_b)
+        for key in ("logits", "softmax", "tokens"):
+            assert torch.equal(b[key], a[key][:k]), (layers, key)
+        assert torch.equal(b["state"], a["state"][:, :k]) and torch.equal(pw_b, pw_a[:k])
+        assert int((b["tokens"] > 0).sum()) > 0
