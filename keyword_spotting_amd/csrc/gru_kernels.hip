@@ -786,6 +786,8 @@ static size_t resident_lds_bytes(int kcx, bool first, bool last) {
     if (first) n += (size_t)64 * xs_stride(kcx) * 4;
     return n;
 }
+constexpr size_t kOneWorkgroupPerCuLds = 82 * 1024;      // > 160 KB / 2
+
 static size_t generic_lds_bytes(int hidden, bool last) {
     size_t n = (size_t)3 * (hidden / 16) * 64 * 16 + (size_t)3 * hidden * 4;
     if (last) n += kEpilogueLdsBytes;
@@ -842,7 +844,10 @@ static hipError_t launch_pipelined(const GruStackParams& sp, size_t lds, hipStre
 }
 
 hipError_t launch_gru_stack_generic_pipelined(const GruStackParams& sp, int hidden, hipStream_t st) {
-    const size_t lds = generic_lds_bytes(hidden, true);
+    // ask for more than half a CU's LDS: one workgroup per CU, so that the L x G workgroups spread over L x G CUs
+    // instead of doubling up on some of them
+    size_t lds = generic_lds_bytes(hidden, true);
+    if (lds < kOneWorkgroupPerCuLds) lds = kOneWorkgroupPerCuLds;
     if (hidden == 64) return launch_pipelined<1>(sp, lds, st);
     if (hidden == 128) return launch_pipelined<2>(sp, lds, st);
     if (hidden == 256) return launch_pipelined<4>(sp, lds, st);
@@ -851,7 +856,10 @@ hipError_t launch_gru_stack_generic_pipelined(const GruStackParams& sp, int hidd
 
 hipError_t launch_gru_layer_generic(const GruLayerParams& p, int hidden, bool first, bool last,
                                     hipStream_t st) {
-    const size_t lds = generic_lds_bytes(hidden, last);
+    size_t lds = generic_lds_bytes(hidden, last);
+    // a time block of an overlapped call (t_stride set): another layer's kernel runs beside this one on another stream;
+    // keep one workgroup per CU or the dispatcher stacks both kernels onto the same CUs (measured: 2.2x slower each)
+    if (p.t_stride != 0 && lds < kOneWorkgroupPerCuLds) lds = kOneWorkgroupPerCuLds;
 #define KWS_GEN(TPW_) \
     do { \
         if (first && last) return launch_with_lds(gru_layer_generic<TPW_, true, true>, p, lds, st); \

@@ -445,6 +445,9 @@ static bool pipeline_eligible(kws_handle h, int B) {
     // AUTO keeps the resident kernels where they exist even when this launch would be faster (H=128, L=2: +10 % at
     // B <= 2048; L=4, B=1024: 2.2x; select it with KWS_KERNEL_GENERIC): the two kernel families round differently in
     // the last bit, and a stream's result must not depend on how many neighbours it is batched or sharded with.
+#ifdef KWS_NO_PIPELINE
+    return false;
+#endif
     if (h->pipe_disabled) return false;
     if (h->cfg.precision != KWS_FP32 || h->cfg.num_layers < 2 || h->kernel_kind == KWS_KERNEL_RESIDENT) return false;
     for (const auto& L : h->layers)
