@@ -541,12 +541,15 @@ int kws_kernel_times(kws_handle h, float* ms_sum, int32_t* launches, int reset) 
 // The kernels are the ones a plain call uses -- a call on frames [t0, t1) with the state carried is bit-identical to
 // the corresponding slice of one long call (tests/test_gpu_parity.py) -- so the result does not depend on whether
 // this path was taken.  Wall time ~ (slowest layer) x (1 + 1/blocks) instead of the sum over layers.
+#ifndef KWS_OVERLAP_MIN_T
+#define KWS_OVERLAP_MIN_T 64
+#endif
 static bool overlap_eligible(kws_handle h, int B, int T) {
     const kws_config& c = h->cfg;
     if (c.precision != KWS_FP32 || c.num_layers < 2 || c.num_layers > 5 || h->profiling) return false;
     if (pipeline_eligible(h, B)) return false;            // the streaming kernel has its own in-kernel pipeline
     const long long groups = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
-    return h->num_cus > 0 && groups * c.num_layers <= h->num_cus && T >= 64;
+    return h->num_cus > 0 && groups * c.num_layers <= h->num_cus && T >= KWS_OVERLAP_MIN_T;
 }
 
 static int step_overlapped(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
@@ -555,6 +558,7 @@ static int step_overlapped(kws_handle h, const float* mel, const float* state_in
     const kws_config& c = h->cfg;
     const int H = c.hidden, L = c.num_layers, C = c.num_classes;
     int nb = T / 32 < 8 ? T / 32 : 8;              // more blocks: less fill/drain, more launch prologues (8: +6 % over 4)
+    if (nb < 2) nb = 2;
     const int Tb = ((T + nb - 1) / nb + 15) & ~15;        // multiple of the epilogue ring
     nb = (T + Tb - 1) / Tb;
     const size_t groups = (size_t)(B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
