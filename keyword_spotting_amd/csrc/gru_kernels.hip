@@ -858,7 +858,8 @@ hipError_t launch_gru_layer_generic(const GruLayerParams& p, int hidden, bool fi
                                     hipStream_t st) {
     size_t lds = generic_lds_bytes(hidden, last);
     // a time block of an overlapped call (t_stride set): another layer's kernel runs beside this one on another stream;
-    // keep one workgroup per CU or the dispatcher stacks both kernels onto the same CUs (measured: 2.2x slower each)
+    // keep one workgroup per CU or the dispatcher stacks both kernels onto the same CUs (measured: 2.2x slower each;
+    // within ONE launch it spreads workgroups by itself, and padding then only costs occupancy when groups > CUs)
     if (p.t_stride != 0 && lds < kOneWorkgroupPerCuLds) lds = kOneWorkgroupPerCuLds;
 #define KWS_GEN(TPW_) \
     do { \
