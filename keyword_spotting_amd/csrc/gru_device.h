@@ -129,9 +129,10 @@ __device__ __forceinline__ f32x2 tanh2(f32x2 x) {
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every frame
-// would then wait for the inter-layer scratch stores and for the x prefetch of the next frame, which
-// no other wave of the group ever reads.
+// Workgroup barrier that orders LDS traffic only: the inter-layer scratch stores and the x prefetch of the next
+// frame, which no other wave of the group ever reads, stay in flight across it.  (hipcc's __syncthreads() is the
+// same two instructions on gfx950 -- it does not wait for global memory either; where a store has to be visible
+// outside the CU before the barrier, the kernels drain vmcnt(0) explicitly.)
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef KWS_ABL_NOBARRIER
