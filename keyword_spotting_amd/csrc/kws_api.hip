@@ -69,7 +69,9 @@ struct kws_model {
     bool pipe_disabled = false;
     // time-blocked overlap of the layers on separate HIP streams (step_overlapped)
     hipStream_t lane_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> ovl_events;      // fine-grained memory unavailable, or a pipelined launch timed out: sequential launches from then on
+    std::vector<hipEvent_t> ovl_events;
+    hipEvent_t ovl_tail[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // end of the last overlapped call, per lane
+    bool ovl_tail_valid = false;      // fine-grained memory unavailable, or a pipelined launch timed out: sequential launches from then on
     // layer-pipelined launch of the generic kernel
     int num_cus = 0;
     int* pipe_ready = nullptr;       // [L][groups] frames published
@@ -418,6 +420,7 @@ int kws_destroy(kws_handle h) {
     if (h->pipe_ready) hipFree(h->pipe_ready);
     if (h->pipe_error_host) hipHostFree(h->pipe_error_host);
     for (auto ev : h->ovl_events) hipEventDestroy(ev);
+    for (auto ev : h->ovl_tail) if (ev) hipEventDestroy(ev);
     for (auto sx : h->lane_stream) if (sx) hipStreamDestroy(sx);
     if (h->oct_aq) hipFree(h->oct_aq);
     if (h->oct_range) hipFree(h->oct_range);
@@ -620,7 +623,12 @@ static int step_overlapped(kws_handle h, const float* mel, const float* state_in
             KWS_HIP(hipEventRecord(done(l, k), sx));
         }
     }
-    for (int l = 1; l < L; ++l) KWS_HIP(hipStreamWaitEvent(st, done(l, nb - 1), 0));           // rejoin the caller's stream
+    for (int l = 1; l < L; ++l) {
+        KWS_HIP(hipStreamWaitEvent(st, done(l, nb - 1), 0));                                   // rejoin the caller's stream
+        if (!h->ovl_tail[l]) KWS_HIP(hipEventCreateWithFlags(&h->ovl_tail[l], hipEventDisableTiming));
+        KWS_HIP(hipEventRecord(h->ovl_tail[l], h->lane_stream[l]));
+    }
+    h->ovl_tail_valid = true;
     return KWS_OK;
 }
 
@@ -635,6 +643,13 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     hipStream_t st = static_cast<hipStream_t>(stream);
     const kws_config& c = h->cfg;
     const int H = c.hidden, L = c.num_layers;
+    if (h->ovl_tail_valid) {
+        // the previous call ran its upper layers on the handle's own streams: whatever stream this call comes in on,
+        // it must not touch the seam buffers (or reallocate them) before those kernels are done
+        for (int l = 1; l < L; ++l)
+            if (h->ovl_tail[l]) KWS_HIP(hipStreamWaitEvent(st, h->ovl_tail[l], 0));
+        h->ovl_tail_valid = false;
+    }
     if (T == 0) {
         if (state_out != state_in)
             KWS_HIP(hipMemcpyAsync(state_out, state_in, (size_t)L * B * H * sizeof(float), hipMemcpyDeviceToDevice, st));
