@@ -226,7 +226,6 @@ gru_layer_resident(const GruLayerParams p) {
         }
     };
     using pinned = std::true_type;
-    using unpinned = std::false_type;
     constexpr int KSPLIT = KCX / 2;
     using k_lo = std::integral_constant<int, 0>;
     using k_mid = std::integral_constant<int, KSPLIT>;
