@@ -73,6 +73,11 @@ enum { KWS_KERNEL_AUTO = 0, KWS_KERNEL_GENERIC = 1, KWS_KERNEL_RESIDENT = 2 };
 enum { KWS_DECODE = 0, KWS_DECODE2 = 1, KWS_DECODE_STRICT = 2 };
 
 const char* kws_version(void);
+/* sizeof(kws_config) / sizeof(kws_frontend_config) as this library was compiled: a binding written in another
+ * language (ctypes, cffi, JNI ...) compares it with its own struct declaration at load time, so a field added here
+ * can never be read past the end of a caller's shorter struct. */
+size_t kws_sizeof_config(void);
+size_t kws_sizeof_frontend_config(void);
 /* Message of the last error raised on this thread ("" if none). */
 const char* kws_last_error(void);
 

@@ -47,6 +47,8 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _SIGNATURES = {
     "kws_version": (ctypes.c_char_p, []),
     "kws_last_error": (ctypes.c_char_p, []),
+    "kws_sizeof_config": (ctypes.c_size_t, []),
+    "kws_sizeof_frontend_config": (ctypes.c_size_t, []),
     "kws_weights_nbytes": (ctypes.c_size_t, [ctypes.POINTER(KwsConfig)]),
     "kws_create": (_i, [ctypes.POINTER(KwsConfig), _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "kws_destroy": (_i, [_vp]),
@@ -90,6 +92,10 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.kws_sizeof_config() != ctypes.sizeof(KwsConfig) or \
+                lib.kws_sizeof_frontend_config() != ctypes.sizeof(KwsFrontendConfig):
+            raise ImportError("%s was built from a different include/kws_amd.h than this binding (struct sizes differ); "
+                              "rebuild it" % LIB_PATH)
         _lib = lib
     return _lib
 

@@ -191,6 +191,8 @@ extern "C" {
 
 const char* kws_version(void) { return "kws_amd 0.1 (gfx950)"; }
 const char* kws_last_error(void) { return g_last_error.c_str(); }
+size_t kws_sizeof_config(void) { return sizeof(kws_config); }
+size_t kws_sizeof_frontend_config(void) { return sizeof(kws_frontend_config); }
 
 size_t kws_weights_nbytes(const kws_config* cfg) {
     int code;

@@ -13,8 +13,8 @@ What is reproduced, per sess.run-sized chunk and per stream:
   * test2: chunked replay of a whole utterance, one ctc_decode at the end (detector.py:254-289)
 
 B independent streams run in lock step (one kws_step per chunk for all of them); the window
-bookkeeping is per stream.  Input is the mel variant of the graph (models/rnn_ctc.py:150-153); the
-PCM front-end is SURVEY 8f next-row 1.
+bookkeeping is per stream.  feed() takes the mel variant of the graph (models/rnn_ctc.py:150-153); feed_pcm() is
+the shipped graph's contract (PCM in, front-end on the device).
 """
 import numpy as np
 import torch
@@ -123,10 +123,10 @@ class HotwordDetector(object):
         carried tail (:179), keeps the new tail (:181-183), runs the in-graph front-end
         (models/rnn_ctc.py:134-149, here `frontend` = keyword_spotting_amd.frontend.MelFrontend) and the
         loop body; VAD looks at the newly captured chunk only (:168)."""
-        chunk = torch.as_tensor(pcm_chunk, dtype=torch.float32)
+        chunk = torch.as_tensor(pcm_chunk)
         if chunk.dim() == 1:
             chunk = chunk.unsqueeze(0)
-        chunk = chunk.to(self.model.device)
+        chunk = buf_to_float(chunk.to(self.model.device))             # int16 PCM -> [-1, 1) as RingBuffer.get does (:74-79)
         if not hasattr(self, "res"):
             self.res = chunk[:, :0]                                   # :125
         data = torch.cat([self.res, chunk], 1)                        # :179

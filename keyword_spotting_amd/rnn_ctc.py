@@ -1,13 +1,18 @@
 """DeployModel -- the streaming inference graph of models/rnn_ctc.py:113-166 as one object backed
-by the HIP kernels (mel-input variant of the graph, models/rnn_ctc.py:150-153).
+by the HIP kernels.
 
     model = DeployModel(config, weights)
     logits, next_state = model.step(mel_chunk, prev_state)        # the north-star surface
 
-or, in the reference's own vocabulary (detector.py:190-193):
+or, in the reference's own vocabulary (detector.py:190-193), with the feed the shipped graph takes --
+`model/inputX:0` is the 1-D PCM chunk (models/rnn_ctc.py:130-134) and the front-end
+(tf_frame -> |rfft| -> mel matmul, :134-149) runs inside the graph:
 
     softmax, state = model.run(['model/softmax:0', 'model/rnn_states:0'],
-                               {'model/inputX:0': mel, 'model/rnn_initial_states:0': state})
+                               {'model/inputX:0': data, 'model/rnn_initial_states:0': state})
+
+The commented mel-input variant of the graph (models/rnn_ctc.py:150-153: inputX = [T, n_mel]) is accepted on
+the same name: a 2-D feed is one stream's mel, a 3-D feed is B streams' mel.
 
 Tensors are torch CUDA tensors and stay on the device; B independent streams are batched:
 mel [B,T,n_mel], state [L,B,H], logits/softmax [B,T,C].
@@ -31,6 +36,7 @@ FETCH_TOKENS = "model/ctc_decode2_tokens:0"     # extension: fused per-frame ctc
 class DeployModel(object):
     def __init__(self, config, weights, device="cuda:0", kernel="auto"):
         self.config = config
+        self._frontend = None
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.InvalidArgumentError(-1, "DeployModel needs a CUDA/HIP device, got %s" % device)
@@ -48,9 +54,20 @@ class DeployModel(object):
 
     # -- lifecycle ---------------------------------------------------------------------------
     def close(self):
+        if getattr(self, "_frontend", None) is not None:
+            self._frontend.close()
+            self._frontend = None
         if getattr(self, "_handle", None) is not None and self._handle.value:
             self._lib.kws_destroy(self._handle)
             self._handle = ctypes.c_void_p()
+
+    @property
+    def frontend(self):
+        """The in-graph audio front-end (models/rnn_ctc.py:134-149), created on first use."""
+        if self._frontend is None:
+            from .frontend import MelFrontend
+            self._frontend = MelFrontend(self.config, device=self.device)
+        return self._frontend
 
     def __del__(self):
         try:
@@ -145,8 +162,12 @@ class DeployModel(object):
         return r["logits"], r["state"]
 
     def run(self, fetches, feed_dict):
-        """tf.Session.run on the frozen graph's tensor names (main.py:339-342).  A 2-D mel feed
-        [T,n_mel] / state [L,1,H] is the reference's batch-1 form; 3-D mel is B streams."""
+        """tf.Session.run on the frozen graph's tensor names (main.py:339-342).
+        model/inputX:0 is, as in the shipped graph, the 1-D float PCM chunk (models/rnn_ctc.py:130-134;
+        detector.py:190-193 feeds `data`): framed, transformed and projected on the mel basis on the device
+        (kws_frontend_run) before kws_step.  Fewer than fft_size samples give zero frames (tf_frame,
+        utils/stft.py:27-81) and the state comes back unchanged.  A 2-D feed [T,n_mel] is the commented
+        mel-input variant (:150-153) at batch 1, a 3-D feed [B,T,n_mel] is B streams (state [L,B,H])."""
         single = isinstance(fetches, str)
         names = [fetches] if single else list(fetches)
         known = (FETCH_SOFTMAX, FETCH_LOGIT, FETCH_STATE)
@@ -159,6 +180,14 @@ class DeployModel(object):
         if FEED_INPUT not in feed_dict or FEED_STATE not in feed_dict:
             raise _lib.InvalidArgumentError(-1, "feeds %s and %s are required" % (FEED_INPUT, FEED_STATE))
         mel = torch.as_tensor(feed_dict[FEED_INPUT])
+        if mel.dim() == 1:
+            if not mel.dtype.is_floating_point:
+                raise _lib.InvalidArgumentError(-1, "model/inputX:0 is a float32 placeholder, got %s "
+                                                "(convert PCM with detector.buf_to_float)" % mel.dtype)
+            mel = self.frontend.forward(mel)                # [T, n_mel]
+        if mel.dim() not in (2, 3):
+            raise _lib.InvalidArgumentError(-1, "model/inputX:0 must be PCM [N], mel [T,%d] or mel [B,T,%d]; got rank %d"
+                                            % (self.config.n_mel, self.config.n_mel, mel.dim()))
         squeeze = mel.dim() == 2
         if squeeze:
             mel = mel.unsqueeze(0)

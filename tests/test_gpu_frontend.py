@@ -175,3 +175,64 @@ def test_carry_form_equals_concatenation_and_streams_like_the_host_loop():
         got = mgr.feed_pcm(torch.from_numpy(piece), fe).cpu().numpy()
         np.testing.assert_array_equal(got, want)
         assert torch.equal(mgr.state, det.state)
+
+
+def test_session_run_takes_the_pcm_feed_of_the_shipped_graph():
+    """models/rnn_ctc.py:130-165 / detector.py:190-193: `model/inputX:0` is the 1-D PCM chunk; the graph frames it,
+    takes |rfft|, projects on the mel basis and runs the GRU stack.  Checked against frontend_oracle + gru_oracle,
+    chunk after chunk with the sample carry of detector.py:179-183 and the state threaded through."""
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    from keyword_spotting_amd import _lib
+    cfg = get_config()
+    w = G.init_weights()
+    m = DeployModel(cfg, w)
+    rng = np.random.default_rng(241)
+    pcm = (rng.standard_normal(3600 * 4) * 0.3).astype(np.float32)
+    state = np.zeros((2, 1, 128), np.float32)
+    res = pcm[:0]
+    ostate = np.zeros((2, 1, 128), np.float64)
+    for c in range(4):
+        data = np.concatenate((res, pcm[3600 * c:3600 * (c + 1)]), 0)            # detector.py:179
+        keep = (len(data) - 400) % 160 + 240                                      # :181-182
+        res = data[-keep:]                                                        # :183
+        softmax, logit, state = m.run(["model/softmax:0", "model/logit:0", "model/rnn_states:0"],
+                                      {"model/inputX:0": data, "model/rnn_initial_states:0": state})
+        t = D.frames_in(len(data))
+        assert tuple(softmax.shape) == (t, 6) and tuple(logit.shape) == (1, t, 6) and tuple(state.shape) == (2, 1, 128)
+        mel = F.melspec(data[None], n_mels=40)
+        want_l, ostate = G.gru_forward(w, mel, ostate, dtype=np.float64)
+        scale = max(1.0, float(np.abs(want_l).max()))
+        assert np.abs(logit.cpu().numpy() - want_l).max() < 1e-4 * scale
+        assert np.abs(softmax.cpu().numpy() - G.softmax(want_l)[0]).max() < 2e-5
+        assert np.abs(state.cpu().numpy() - ostate).max() < 1e-4
+    # fewer samples than one frame: zero frames, state untouched (tf_frame, utils/stft.py:27-81)
+    sm, st = m.run(["model/softmax:0", "model/rnn_states:0"],
+                   {"model/inputX:0": pcm[:399], "model/rnn_initial_states:0": state})
+    assert tuple(sm.shape) == (0, 6) and torch.equal(st, state)
+    with pytest.raises(_lib.InvalidArgumentError):                               # float32 placeholder
+        m.run("model/softmax:0", {"model/inputX:0": np.zeros(3600, np.int16), "model/rnn_initial_states:0": state})
+    with pytest.raises(_lib.InvalidArgumentError):
+        m.run("model/softmax:0", {"model/inputX:0": np.zeros((1, 2, 3, 40), np.float32), "model/rnn_initial_states:0": state})
+
+
+def test_int16_pcm_gives_the_same_decisions_in_both_detector_classes():
+    """RingBuffer.get (detector.py:74-79) hands the loop int16 PCM scaled by 2^-15: HotwordDetector.feed_pcm and
+    StreamManager.feed_pcm convert it the same way, so VAD decisions, mel and triggers agree."""
+    from keyword_spotting_amd.detector import HotwordDetector, StreamManager
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg, fe = _frontend()
+    w = G.init_weights()
+    w["Wfc"] = (w["Wfc"] * 3).astype(np.float32)
+    rng = np.random.default_rng(251)
+    pcm16 = (rng.standard_normal((4, 3600 * 8)) * 3000).clip(-32768, 32767).astype(np.int16)
+    pcm16[1, 3600 * 2:3600 * 4] = (pcm16[1, 3600 * 2:3600 * 4] // 4000)           # near-silent chunks: sum|x| < 30
+    det = HotwordDetector(DeployModel(cfg, w), batch=4, label="12")
+    mgr = StreamManager(DeployModel(cfg, w), 4, label="12")
+    for c in range(8):
+        piece = pcm16[:, 3600 * c:3600 * (c + 1)]
+        want = np.zeros(4, np.int32)
+        want[det.feed_pcm(torch.from_numpy(piece), fe)] = 1
+        got = mgr.feed_pcm(torch.from_numpy(piece), fe).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        assert torch.equal(mgr.state, det.state)
