@@ -27,21 +27,6 @@ PEAK_FP32_TFLOPS = 157.3                                                      # 
 PEAK_HBM_GBS = 8000.0
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
-    (profiles/r*_pmc.json, written by tools/prof.sh on the same bench command; FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE).  None when no profile has been committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-    if not files:
-        return None, None
-    data = json.load(open(files[-1]))
-    for k, c in data.items():
-        if kernel_substr in k and "hbm_bytes_per_launch" in c:
-            return c["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
-    return None, None
-
-
 def secondary_lines(device):
     """Informational figures for the other BASELINE configs, measured after the timed region on rank 0 (never part of
     `value`): the bf16 and int8 variants of the headline workload, the end-to-end PCM -> trigger streaming loop and
@@ -97,7 +82,29 @@ def secondary_lines(device):
     return out
 
 
-def cpu_baseline(cfg, w, seconds_budget=10.0):
+def usable_cores():
+    """(threads to use, logical CPUs visible, cgroup quota or None): floor of the cgroup v2/v1 CPU quota when there is
+    one, else the size of the affinity mask."""
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except Exception:
+        visible = os.cpu_count() or 1
+    quota = None
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:
+        try:
+            cq = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            cp = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = cq / cp if cq > 0 else None
+        except Exception:
+            pass
+    cores = visible if quota is None else max(1, min(visible, int(quota)))
+    return cores, visible, quota
+
+
+def cpu_baseline(cfg, w, seconds_budget=25.0):
     """The oracle timed on this host (reference TF-1.x is not executable here or on the GPU box):
     (ii) tight C restatement, 1 core and all cores; (i) torch-CPU eager op-by-op = 'TF-CPU stand-in'.
     Workload = BASELINE config 1: batch 1, 300 frames, state round trip, greedy decode."""
@@ -113,7 +120,6 @@ def cpu_baseline(cfg, w, seconds_budget=10.0):
         orc = obuild.load()
     blob = G.weights_to_blob(w)
     ctuple = (cfg.n_mel, cfg.hidden_size, cfg.num_layers, cfg.num_classes, 0, -1.0)
-    cores = os.cpu_count() or 1
     mel1 = G.synthetic_mel(1, 300, cfg.n_mel, seed=1)
     st1 = np.zeros((cfg.num_layers, 1, cfg.hidden_size), np.float32)
 
@@ -134,31 +140,17 @@ def cpu_baseline(cfg, w, seconds_budget=10.0):
         return n * streams * 300 / (time.perf_counter() - t0)
 
     c1 = rate(1, 1, seconds_budget / 5)
-    # the box may expose more logical CPUs than the job's cgroup lets it use: sweep the OpenMP team size
-    # and keep the best (one independent batch-1 stream per thread at a time)
-    best_thr, call = 1, c1
-    thr = 2
-    while thr <= cores:
-        r = rate(thr, thr * 8, seconds_budget / 25)
-        if r > call:
-            best_thr, call = thr, r
-        thr *= 2
-    call = max(call, rate(best_thr, best_thr * 8, seconds_budget / 5))
-    visible = cores
-    cores = best_thr
-    quota = None
-    try:
-        q = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
-    except Exception:
-        pass
+    # the OpenMP team is pinned to what this job may actually use -- the cgroup CPU quota (the box shows more logical
+    # CPUs than that), else the affinity mask -- so the figure reproduces from run to run
+    cores, visible, quota = usable_cores()
+    call = rate(cores, cores * 8, seconds_budget * 0.4) if cores > 1 else c1
     # torch eager, op by op, batch 1, 22-frame chunks with the state round-tripping through numpy
     torch.set_num_threads(1)
     tw = TE.to_torch(w)
     melt = torch.from_numpy(mel1)
     frames, t0 = 0, time.perf_counter()
     state = torch.zeros(cfg.num_layers, 1, cfg.hidden_size)
-    while time.perf_counter() - t0 < seconds_budget / 2:
+    while time.perf_counter() - t0 < seconds_budget / 5:
         for pos in range(0, 300, 22):
             lg, sm, state = TE.gru_forward(tw, melt[:, pos:pos + 22], state)
             state = torch.from_numpy(state.numpy().copy())
@@ -167,14 +159,27 @@ def cpu_baseline(cfg, w, seconds_budget=10.0):
     return {"value": call, "unit": "mel-frames/s", "cores": cores, "kind": "port",
             "sample": "oracle/kws_oracle.c (restatement of reference semantics; TF-1.x not executable): "
                       "%d independent batch-1 streams x 300 frames + ctc_decode2 per pass, OpenMP team of %d "
-                      "(best of a power-of-two sweep; %d logical CPUs visible, cgroup quota %s), ~%.0fs"
-                      % (cores * 8, cores, visible, quota, seconds_budget / 5),
+                      "(= the job's cgroup CPU quota %s; %d logical CPUs visible), ~%.0fs"
+                      % (cores * 8, cores, quota, visible, seconds_budget * 0.4),
             "single_core_value": c1,
             "eager_stand_in": {"value": eager, "cores": 1, "what": "torch-CPU op-by-op GRUCell loop, batch 1, 22-frame "
                                "chunks, state round trip (analogue of the reference's per-op TF dispatch)"}}
 
 
-def main():
+def pmc_traffic_all():
+    """{kernel name: HBM bytes per launch} for every kernel of the latest committed PMC pass, and its path."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return {}, None
+    data = json.load(open(files[-1]))
+    return {k: c["hbm_bytes_per_launch"] for k, c in data.items() if "hbm_bytes_per_launch" in c}, os.path.relpath(files[-1], ROOT)
+
+
+def main(argv=None, model_factory=None):
+    """model_factory(cfg, weights, device, kernel) -> object with DeployModel's surface; tests pass a stub that needs no
+    GPU so that THIS function -- launcher, rank/device plumbing, barriers, reduction, the JSON line -- is what the
+    world_size-2 gloo test executes (tests/test_dist_gloo.py).  The driver never passes one."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -187,7 +192,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the "
                     "multi-process path on a box with fewer GPUs than ranks")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    stub = model_factory is not None
 
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         # not under torchrun: start one rank per GPU as CHILD processes (nothing here has touched the GPU yet)
@@ -198,14 +204,16 @@ def main():
         port = sock.getsockname()[1]
         sock.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + \
+              (sys.argv[1:] if argv is None else list(argv))
         raise SystemExit(subprocess.call(cmd))
 
     import torch
     from keyword_spotting_amd import get_config, sharding, weights
-    from keyword_spotting_amd.rnn_ctc import DeployModel
 
     rank, local_rank, world = sharding.env_rank_world()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -215,15 +223,24 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local_rank % torch.cuda.device_count())
+    if stub:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        device = torch.device("cuda", local_rank % torch.cuda.device_count())
+        torch.cuda.set_device(device)
+        from keyword_spotting_amd.rnn_ctc import DeployModel
+        model_factory = lambda cfg_, w_, dev_, kern_: DeployModel(cfg_, w_, device=dev_, kernel=kern_)   # noqa: E731
     sync_device = device if args.dist_backend == "nccl" else torch.device("cpu")
-    torch.cuda.set_device(device)
+
+    def device_sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
 
     cfg = get_config(precision=args.precision)
     w = weights.init_weights(cfg, seed=0)
-    model = DeployModel(cfg, w, device=device, kernel=args.kernel)
+    model = model_factory(cfg, w, device, args.kernel)
     B, T = args.batch, args.frames
     model.reserve(B, T)
     gen = torch.Generator(device=device).manual_seed(sharding.shard_seed(1, rank))
@@ -239,20 +256,21 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(device)
+    device_sync()
     model.set_profiling(True)
     model.kernel_times(reset=True)
     sharding.barrier(dist, sync_device)
-    torch.cuda.synchronize(device)
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize(device)
+    device_sync()
     sharding.barrier(dist, sync_device)
     elapsed = time.perf_counter() - t0
     ktimes = model.kernel_times(reset=True)
     model.set_profiling(False)
     frames, seconds = sharding.reduce_throughput(dist, B * T * args.steps, elapsed, sync_device)
+    ranks_seen = sharding.count_ranks(dist, sync_device)
 
     if rank == 0:
         value = frames / seconds
@@ -263,17 +281,23 @@ def main():
         dom_flops = FLOP_PER_FRAME["total"] if args.precision == "bf16" else FLOP_PER_FRAME["layer"][dom]
         achieved = dom_flops * B * T / (dom_ms * 1e-3) / 1e12
         peak = 2500.0 if args.precision == "bf16" else PEAK_FP32_TFLOPS
+        bound = "mfma"
         if args.precision == "int8" and dom >= 1:
             # exact emulation of the reference's int16-saturating pair sums runs on the packed-int16 VALU
-            # (3 instructions per 2 pairs = 8 int ops / 3 lane-instructions); MFMA i8 cannot saturate
-            peak = 256 * 64 * 2.4e9 * (8.0 / 3.0) / 1e12
+            # (3 instructions per 2 pairs = 8 int ops / 3 lane-instructions)
+            peak, bound = 256 * 64 * 2.4e9 * (8.0 / 3.0) / 1e12, "valu-pk-i16 (secondary line)"
         all_ms = sum(k[0] / max(k[1], 1) for k in ktimes)
         dom_name = "gru_layer_resident<%s>" % ("10, true, false" if dom == 0 else "32, false, true")
-        traffic, traffic_src = (pmc_traffic(dom_name) if model.kernel != "generic" and args.precision == "fp32"
-                                else (None, None))
+        pmc, traffic_src = pmc_traffic_all() if getattr(model, "kernel", "") != "generic" and args.precision == "fp32" else ({}, None)
+        traffic = next((v for k, v in pmc.items() if dom_name in k), None)
+        pmc_step = sum(v for k, v in pmc.items() if "gru_layer_resident" in k) if pmc else None
+        path_bytes = BYTES_PER_FRAME * B * T                  # 160 mel in + 24 logits (+24 softmax +1 token) out
+        # the dominant kernel's own share of those boundary bytes; the fp32 inter-layer seam (512 B/frame written by
+        # layer 0 and read back by layer 1) is INTERNAL traffic, not algorithmic work -- it is what `traffic` exceeds by
+        dom_alg = ((160 if dom == 0 else 49) if args.precision != "bf16" else BYTES_PER_FRAME) * B * T
         line = {
             "metric": "mel-frames/s (real-time 10 ms-hop audio streams sustained = value/100)",
-            "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "mel-frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 (secondary line; headline is f32)",
                                            "int8": "u8 x s8 -> sat i16 -> i32, layer 0 f32 (secondary line; headline is f32)"}[args.precision],
@@ -282,21 +306,25 @@ def main():
                                    "per step, %s, state carried on device, logits+softmax+fused ctc_decode2"
                                    % (B, T, {"fp32": "fp32", "bf16": "configs[2] bf16 variant", "int8": "configs[2] octbit int8 variant"}[args.precision]),
                        "streams_per_gpu": B, "frames_per_step": T, "parallelism": "utterance-dp%d" % world,
-                       "kernel": model.kernel},
+                       "kernel": getattr(model, "kernel", "stub")},
             "realtime_streams": value / 100.0,
-            "roofline": {"bound": "valu-pk-i16 (secondary line)" if args.precision == "int8" and dom >= 1 else "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": (209 if args.precision == "bf16" else (512 + 49 if dom else 160 + 512)) * B * T,
+                         "algorithmic_bytes_per_launch": dom_alg,
+                         "seam_bytes_per_launch": 0 if args.precision == "bf16" else 512 * B * T,
+                         "path_algorithmic_bytes_per_step": path_bytes,
+                         "pmc_bytes_per_step": pmc_step,
+                         "pmc_over_algorithmic": (pmc_step / path_bytes) if pmc_step else None,
                          "kernel": ("gru_stack_bf16 (both layers fused)" if args.precision == "bf16" else
                                     "gru_layer_octbit layer %d + projection" % dom if args.precision == "int8" and dom >= 1 else
-                                    "gru_layer_%s layer %d" % ("resident" if model.kernel != "generic" else "generic", dom)),
+                                    "gru_layer_%s layer %d" % ("resident" if getattr(model, "kernel", "") != "generic" else "generic", dom)),
                          "kernel_ms": dom_ms, "launches": ktimes[dom][1],
                          "all_layers_tflops": FLOP_PER_FRAME["total"] * B * T / (all_ms * 1e-3) / 1e12,
                          "per_layer_ms": [k[0] / max(k[1], 1) for k in ktimes],
                          "hbm_algorithmic_GBps": BYTES_PER_FRAME * B * T / (all_ms * 1e-3) / 1e9,
                          "hbm_frac_of_peak": BYTES_PER_FRAME * B * T / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not stub:
             try:
                 line["secondary"] = secondary_lines(device)
             except Exception as exc:          # informational only: never lose the headline line over it

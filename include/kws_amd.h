@@ -22,7 +22,9 @@
  *     tensor's data_ptr) unless the parameter is documented as host memory.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All work is
  *     enqueued asynchronously on it; no entry point synchronises the device except kws_create /
- *     kws_destroy / kws_kernel_times.
+ *     kws_destroy / kws_kernel_times / kws_reserve -- and kws_step only when the call needs more scratch
+ *     than kws_reserve or any earlier call provided (it then grows the handle's scratch block, which
+ *     waits for the device once; kws_scratch_stats counts those events).
  *   - return value: KWS_OK or a negative kws_status.  No exceptions, no abort.  The message for the
  *     last failure on the calling thread is kws_last_error().
  *   - a handle is immutable after kws_create except for its scratch buffer and profiling slots:
@@ -95,8 +97,18 @@ int kws_destroy(kws_handle h);
  * (hidden == 128 and n_mel in {40, 60}), else the generic ones (hidden 64/128/256, any n_mel).
  * RESIDENT on an unsupported shape -> KWS_ERR_UNSUPPORTED.  Ignored by the bf16 stack. */
 int kws_set_kernel(kws_handle h, int kind);
-/* Pre-sizes the inter-layer scratch for B streams x T frames so kws_step never allocates. */
+/* Pre-sizes the handle's scratch for calls of up to B streams x T frames: afterwards kws_step on any shape whose
+ * scratch fits never allocates or synchronises, whichever launch layout it picks (sequential layers, layers overlapped
+ * on HIP streams, layer-pipelined launch).  The scratch only grows. */
 int kws_reserve(kws_handle h, int B, int T);
+/* bytes_reserved: device scratch currently held for inter-layer seams; allocations: how many times it (or another
+ * batch-sized side buffer) was (re)allocated -- each of those synchronised the device.  Either pointer may be NULL. */
+int kws_scratch_stats(kws_handle h, size_t* bytes_reserved, int32_t* allocations);
+/* KWS_OK, or the error a finished asynchronous step of this handle raised on the device (today: a layer-pipelined
+ * launch whose wait for the layer below timed out -- the results of that step are invalid).  Does not synchronise: to
+ * validate a given step, synchronise its stream first.  The same condition is also reported by the next kws_step,
+ * by kws_kernel_times and by kws_destroy, whichever comes first; reporting clears it. */
+int kws_poll_error(kws_handle h);
 
 /* Advances B independent streams by T frames (one 10 ms hop each).
  *   mel        [B,T,I]  f32, 16-byte aligned         model/inputX:0 (mel variant), batch-major
@@ -165,7 +177,8 @@ int kws_frontend_run_carry(kws_frontend_handle h, const float* carry, int n_carr
 int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host);
 
 /* Device-side decode window of the streaming loop (detector.py:122,168-209; utils/queue.py): per stream a
- * bounded FIFO of up to `max_chunks` softmax chunks (each <= max_frames frames).  ctc_decode2's per-frame rule
+ * bounded FIFO of up to `max_chunks` (1..64) softmax chunks (each <= max_frames frames; 3 * max_chunks *
+ * round_up(max_frames, 16) bytes must fit 64 KiB, else KWS_ERR_UNSUPPORTED).  ctc_decode2's per-frame rule
  * (argmax over classes 1..C-2, strictly above `thres`) is a function of the frame alone, so the window stores each
  * frame's word rather than its softmax row; `thres` is therefore fixed per handle.  kws_window_step, per stream:
  *   clear_before[b] != 0 -> empty the window first (silence: detector.py:171-177);

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "kws_destroy": (_i, [_vp]),
     "kws_set_kernel": (_i, [_vp, _i]),
     "kws_reserve": (_i, [_vp, _i, _i]),
+    "kws_scratch_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int32)]),
+    "kws_poll_error": (_i, [_vp]),
     "kws_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "kws_set_profiling": (_i, [_vp, _i]),
     "kws_kernel_times": (_i, [_vp, _vp, _vp, _i]),

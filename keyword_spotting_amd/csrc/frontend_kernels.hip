@@ -266,12 +266,10 @@ hipError_t launch_carry_tail(const float* carry, int n_carry, const float* chunk
 
 template <int UPW>
 static hipError_t launch_upw(const FrontendParams& p, unsigned grid, size_t lds, hipStream_t st) {
-    static size_t granted = 0;
-    if (lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mel_frontend_kernel<UPW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsGrant granted;             // per kernel instantiation (one static per template instance) and device
+    {
+        const hipError_t e = grant_dynamic_lds(mel_frontend_kernel<UPW>, granted, lds);
         if (e != hipSuccess) return e;
-        granted = lds;
     }
     hipLaunchKernelGGL(mel_frontend_kernel<UPW>, dim3(grid), dim3(256), lds, st, p);
     return hipGetLastError();

@@ -443,12 +443,10 @@ bool gru_bf16_supported(int hidden, int n_mel, int layers) {
 template <int KX0, int NL>
 static hipError_t launch_bf16(const GruBf16Params& p, hipStream_t st) {
     const size_t lds = gru_bf16_lds_bytes(KX0, NL);
-    static size_t granted = 0;
-    if (lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_stack_bf16<KX0, NL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsGrant granted;             // per kernel instantiation (one static per template instance) and device
+    {
+        const hipError_t e = grant_dynamic_lds(gru_stack_bf16<KX0, NL>, granted, lds);
         if (e != hipSuccess) return e;
-        granted = lds;
     }
     const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
     hipLaunchKernelGGL((gru_stack_bf16<KX0, NL>), dim3(groups), dim3(256), lds, st, p);

@@ -13,48 +13,12 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 // sigma(x) = 1/(1+e^-x).  v_exp_f32 path: abs error <= 3e-7 on [-30,30]; saturates cleanly.
 __device__ __forceinline__ float sigmoid_f(float x) {
-#ifdef KWS_ABL_NOVALU
-    return x * 0.001f;
-#else
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-#endif
 }
 // tanh(x) = 1 - 2/(1+e^{2x}); abs error <= 3e-7, exact limits +-1.
 __device__ __forceinline__ float tanh_f(float x) {
-#ifdef KWS_ABL_NOVALU
-    return x * 0.001f;
-#else
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
-#endif
 }
-#if defined(KWS_TIMING) && defined(KWS_ABL_NOBARRIER)
-#define KWS_TIMING_BAR() do {} while (0)
-#else
-#define KWS_TIMING_BAR() __builtin_amdgcn_s_barrier()
-#endif
-#if defined(KWS_TIMING)
-#define KWS_TS(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); \
-    fine_[i] += tn_ - tfine_; tfine_ = tn_; asm volatile("" ::: "memory"); } while (0)
-#else
-#define KWS_TS(i) do {} while (0)
-#endif
-#if defined(KWS_TIMING)
-// timing variant: s_memtime around each barrier (lgkmcnt is drained there anyway)
-#define KWS_SYNC_T(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long ta_ = __builtin_readcyclecounter(); \
-    KWS_TIMING_BAR(); const unsigned long long tb_ = __builtin_readcyclecounter(); \
-    seg_[i] += ta_ - tlast_; wait_[i] += tb_ - ta_; tlast_ = tb_; asm volatile("" ::: "memory"); } while (0)
-#endif
-#if defined(KWS_ABL_NOBARRIER)
-#define KWS_SYNC() __builtin_amdgcn_sched_barrier(0)
-#elif defined(KWS_ABL_WAITONLY)
-#define KWS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
-#elif defined(KWS_ABL_BARONLY)
-#define KWS_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(KWS_ABL_SYNCTHREADS)
-#define KWS_SYNC() __syncthreads()
-#else
-#define KWS_SYNC() lds_barrier()
-#endif
 // MFMA whose A operand (a resident weight fragment) is read straight from the AGPR half of the
 // unified register file.  hipcc only ever parks such values in AGPRs as spills and re-reads them with
 // v_accvgpr_read + s_nop (39 cycles per MFMA instead of 32, tools/ubench/mfma_issue.hip); the "a"
@@ -100,9 +64,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // back-to-back transcendental and +14 for an isolated one), so the ops are clustered, packed
 // (v_pk_mul/add/fma_f32) and kept to the minimum count: sigmoid = pk_mul, 2 exp, pk_add, 2 rcp.
 __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
-#ifdef KWS_ABL_NOVALU
-    return x * 0.001f;
-#endif
     const f32x2 t = x * -kLog2e;
     f32x2 e;
     e.x = __builtin_amdgcn_exp2f(t.x);
@@ -114,9 +75,6 @@ __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
     return r;
 }
 __device__ __forceinline__ f32x2 tanh2(f32x2 x) {
-#ifdef KWS_ABL_NOVALU
-    return x * 0.001f;
-#endif
     const f32x2 t = x * (2.0f * kLog2e);
     f32x2 e;
     e.x = __builtin_amdgcn_exp2f(t.x);
@@ -135,9 +93,7 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // outside the CU before the barrier, the kernels drain vmcnt(0) explicitly.)
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef KWS_ABL_NOBARRIER
     __builtin_amdgcn_s_barrier();
-#endif
     asm volatile("" ::: "memory");
 }
 // ------------------------------------------------------------------------------------------------

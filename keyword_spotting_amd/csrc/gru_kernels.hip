@@ -194,9 +194,6 @@ gru_layer_resident(const GruLayerParams p) {
         if constexpr (KCX % 2 == 1) dst[KCX - 1] = row[KCX - 1];
     };
     auto load_x_slice = [&](float (&dst)[KCX], int t_req, const int sl) {   // upper layers; sl: unrolled constant
-#ifdef KWS_ABL_NOXLOAD
-        return;
-#endif
         if constexpr (!FIRST) {
             const int t = t_req < T ? t_req : T - 1;
             const float4 v = xprev[((size_t)t * NT + sl) * 64];
@@ -241,27 +238,19 @@ gru_layer_resident(const GruLayerParams p) {
     };
 
     __syncthreads();
-#ifdef KWS_TIMING
-    unsigned long long seg_[2] = {0, 0}, wait_[2] = {0, 0}, tlast_ = __builtin_readcyclecounter();
-    const unsigned long long tstart_ = tlast_;
-    unsigned long long fine_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tfine_ = tlast_;
-#endif
     f32x4 hb_a, hb_b;            // exchange-read pipeline registers (two float4 in flight)
 
     // One frame (xcur == xnxt == the single B-operand buffer: x(t+1) lands in it during this frame).
     auto frame = [&](int t, float (&xcur)[KCX], float (&xnxt)[KCX]) {
-        KWS_TS(0);            // [B2 .. here]: hb reads + post-barrier cand_x
         // gates, h-part:  acc_{r,u} += Wg[I:,:]^T h_{t-1}   (hb_a/hb_b were fetched behind cand_x);
         // one slice of x(t+1) is requested per group
         mfma_prefence(acc_r[0], acc_u[0], acc_r[1], acc_u[1]);
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const f32x4 hb = (nn & 1) ? hb_b : hb_a;
-#ifndef KWS_ABL_NOLDSB
             if (nn + 2 < NT) {
                 if (nn & 1) hb_b = hbuf[(nn + 2) * 64 + lane]; else hb_a = hbuf[(nn + 2) * 64 + lane];
             }
-#endif
             if constexpr (FIRST) { if (nn == 0) coop_issue(t + 2); } else load_x_slice(xnxt, t + 1, nn);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -275,7 +264,6 @@ gru_layer_resident(const GruLayerParams p) {
             }
         }
         mfma_fence(acc_r[0], acc_u[0], acc_r[1], acc_u[1]);
-        KWS_TS(1);            // gates_h
         if constexpr (FIRST) read_xs(xcur);          // x(t+1), committed to LDS during frame t-1
         // ---- region A: the 16 sigmoids as one VALU cluster (r first so r(.)h reaches LDS early), then the
         // first half of frame t+1's gate x-part as cover for the exchange
@@ -298,53 +286,29 @@ gru_layer_resident(const GruLayerParams p) {
         for (int j = 0; j < 2; ++j) { acc_r[j] = bias_r[j]; acc_u[j] = bias_u[j]; }
         __builtin_amdgcn_sched_barrier(0);
         gates_x_part(xcur, k_lo{}, k_mid{}, pinned{});
-        KWS_TS(2);            // region A
-#ifdef KWS_TIMING
-        KWS_SYNC_T(0);
-#else
-        KWS_SYNC();           // #1: r(.)h visible; every wave is done reading hbuf
-#endif
+        lds_barrier();           // #1: r(.)h visible; every wave is done reading hbuf
         hb_a = rhbuf[0 * 64 + lane];
         hb_b = rhbuf[1 * 64 + lane];
-        KWS_TS(3);            // barrier 1
         gates_x_part(xcur, k_mid{}, k_hi{}, pinned{});     // second half hides the rhbuf read latency
-        KWS_TS(4);            // gates_x second half
 
         // candidate, h-part:  acc_c += Wc[I:,:]^T (r (.) h_{t-1})
-#ifdef KWS_EXP_CAND4
-        f32x4 acc_c2[2] = {splat4(0.f), splat4(0.f)};
-#endif
         mfma_prefence(acc_c[0], acc_c[1]);
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const f32x4 rb = (nn & 1) ? hb_b : hb_a;
-#ifndef KWS_ABL_NOLDSB
             if (nn + 2 < NT) {
                 if (nn & 1) hb_b = rhbuf[(nn + 2) * 64 + lane]; else hb_a = rhbuf[(nn + 2) * 64 + lane];
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kc = 4 * nn + e;
                 const float rv = rb[e];
-#ifdef KWS_EXP_CAND4
-                if (e & 1) { KWS_MFMA_A(acc_c2[0], wch[0][kc], rv); KWS_MFMA_A(acc_c2[1], wch[1][kc], rv); }
-                else { KWS_MFMA_A(acc_c[0], wch[0][kc], rv); KWS_MFMA_A(acc_c[1], wch[1][kc], rv); }
-#else
                 KWS_MFMA_A(acc_c[0], wch[0][kc], rv);
                 KWS_MFMA_A(acc_c[1], wch[1][kc], rv);
-#endif
             }
         }
-#ifdef KWS_EXP_CAND4
-        mfma_fence(acc_c[0], acc_c[1], acc_c2[0], acc_c2[1]);
-        acc_c[0] += acc_c2[0];
-        acc_c[1] += acc_c2[1];
-#else
         mfma_fence(acc_c[0], acc_c[1]);
-#endif
-        KWS_TS(5);            // cand_h
         // ---- region B: tanh + state update as one VALU cluster
         const unsigned live = t < len_s ? 0xffffffffu : 0u;   // dynamic_rnn copy-through past seq_len
         f32x4 hout[2];
@@ -396,12 +360,7 @@ gru_layer_resident(const GruLayerParams p) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NPRE>(cand_x_mfma);     // most of frame t+1's candidate x-part covers the LDS write
         __builtin_amdgcn_sched_barrier(0);
-        KWS_TS(6);            // region B + writes + fc
-#ifdef KWS_TIMING
-        KWS_SYNC_T(1);
-#else
-        KWS_SYNC();           // #2: h_t visible; every wave is done reading rhbuf
-#endif
+        lds_barrier();           // #2: h_t visible; every wave is done reading rhbuf
         hb_a = hbuf[0 * 64 + lane];
         hb_b = hbuf[1 * 64 + lane];
         FoldRegs fold;
@@ -410,7 +369,6 @@ gru_layer_resident(const GruLayerParams p) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<NPRE, NCX>(cand_x_mfma);   // the rest of frame t+1's candidate x-part hides the hbuf read
         __builtin_amdgcn_sched_barrier(0);
-#ifndef KWS_ABL_NOFLUSH
         if (LAST) {
             if (folder) epilogue_fold_store(epi, t, lane, fold);
             if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
@@ -419,7 +377,6 @@ gru_layer_resident(const GruLayerParams p) {
                 epilogue_flush(p, epi, group, t0, t - t0 + 1, w, lane, t == T - 1);
             }
         }
-#endif
     };
 
     if (T > 0) {
@@ -447,15 +404,6 @@ gru_layer_resident(const GruLayerParams p) {
     }
     for (int t = 0; t < T; ++t) frame(t, xbuf0, xbuf0);
 
-#ifdef KWS_TIMING
-    if (p.dbg && lane == 0) {
-        unsigned long long* d = p.dbg + ((size_t)group * 4 + w) * 8;
-        d[0] = seg_[0]; d[1] = wait_[0]; d[2] = seg_[1]; d[3] = wait_[1];
-        d[4] = __builtin_readcyclecounter() - tstart_; d[5] = T;
-        unsigned long long* f = p.dbg + (size_t)4096 * 4 * 8 + ((size_t)group * 4 + w) * 8;
-        for (int i = 0; i < 8; ++i) f[i] = fine_[i];
-    }
-#endif
     if (bvalid) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -585,9 +533,6 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
             // cache-wide acquire is needed -- an agent-scope acquire invalidates the L2 and with it the weight
             // stream of every workgroup on the XCD, once per frame (measured: slower than the sequential launches).
             int spins = 0;
-#ifdef KWS_PIPE_NOWAIT
-            if (false)
-#endif
             while (__hip_atomic_load(p.ready_in + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= t) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1 << 24)) { if (lane == 0) *reinterpret_cast<volatile int*>(p.pipe_error) = 1; break; }
@@ -803,12 +748,10 @@ bool gru_resident_supported(int hidden, int in_dim, bool first) {
 
 template <typename K>
 static hipError_t launch_with_lds(K kernel, const GruLayerParams& p, size_t lds, hipStream_t st) {
-    static size_t granted = 0;           // per kernel instantiation (one static per template instance)
-    if (lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsGrant granted;             // per kernel instantiation (one static per template instance) and device
+    {
+        const hipError_t e = grant_dynamic_lds(kernel, granted, lds);
         if (e != hipSuccess) return e;
-        granted = lds;
     }
     const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
     hipLaunchKernelGGL(kernel, dim3(groups), dim3(256), lds, st, p);
@@ -829,12 +772,10 @@ hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool l
 
 template <int TPW>
 static hipError_t launch_pipelined(const GruStackParams& sp, size_t lds, hipStream_t st) {
-    static size_t granted = 0;
-    if (lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_stack_generic_pipelined<TPW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsGrant granted;             // per kernel instantiation (one static per template instance) and device
+    {
+        const hipError_t e = grant_dynamic_lds(gru_stack_generic_pipelined<TPW>, granted, lds);
         if (e != hipSuccess) return e;
-        granted = lds;
     }
     const int per = sp.xcd_affine ? 8 / sp.L : 0;
     const int grid = sp.xcd_affine ? 8 * ((sp.G + per - 1) / per) : sp.G * sp.L;

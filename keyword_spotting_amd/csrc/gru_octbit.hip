@@ -230,14 +230,7 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
 
     load_x(0);
     __syncthreads();
-#ifdef KWS_TIMING
-    unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tl_ = __builtin_readcyclecounter();
-#define OCT_TS(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn_ = __builtin_readcyclecounter(); \
-    ph_[i] += tn_ - tl_; tl_ = tn_; asm volatile("" ::: "memory"); } while (0)
-#else
 #define OCT_TS(i) do {} while (0)
-#endif
 
     for (int t = 0; t < T; ++t) {
         if (t > 0) store_out(t - 1);
@@ -357,10 +350,6 @@ __global__ void __launch_bounds__(512) gru_layer_octbit_kernel(const GruOctbitPa
         lds_barrier();
         OCT_TS(11);
     }
-#ifdef KWS_TIMING
-    if (p.dbg && lane == 0)
-        for (int i = 0; i < 12; ++i) p.dbg[((size_t)G * 8 + w) * 12 + i] = ph_[i];
-#endif
     store_out(T - 1);
     for (int i = tid; i < 16 * 128; i += 512) {
         const int s = i >> 7, n = i & 127;
@@ -516,12 +505,10 @@ size_t gru_octbit_lds_bytes() { return (size_t)(3 * 16 * kHS + 16384 + 32 + 32 +
 
 hipError_t launch_gru_layer_octbit(const GruOctbitParams& p, hipStream_t st) {
     const int groups = (p.B + 15) / 16;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_layer_octbit_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)gru_octbit_lds_bytes());
+    static LdsGrant granted;
+    {
+        const hipError_t e = grant_dynamic_lds(gru_layer_octbit_kernel, granted, gru_octbit_lds_bytes());
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(gru_layer_octbit_kernel, dim3(groups), dim3(512), gru_octbit_lds_bytes(), st, p);
     return hipGetLastError();

@@ -63,9 +63,15 @@ struct kws_model {
     int32_t* oct_prev = nullptr;     // [B] copy of prev_word
     size_t oct_groups = 0;
     float* d_weights = nullptr;
-    float4* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // seam l = scratch[l % nscratch]
+    // Inter-layer seams.  ONE device allocation per memory kind that only ever grows (kws_reserve or the first call that
+    // needs more); each kws_step carves the buffers of its launch layout out of it -- sequential (1-2 buffers of T
+    // frames), layers overlapped on HIP streams (2(L-1) buffers of a time block), layer-pipelined (L-1 fine-grained
+    // buffers) -- so alternating layouts never reallocates, and a step within the reserved size never synchronises.
+    struct Arena { char* base = nullptr; size_t bytes = 0; };
+    Arena arena, arena_fine;
+    int scratch_allocs = 0;          // (re)allocations so far; each one synchronised the device (kws_scratch_stats)
+    float4* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // this call's seams: l -> scratch[l % nscratch]
     int nscratch = 0;
-    bool scratch_fine = false;
     bool pipe_disabled = false;
     // time-blocked overlap of the layers on separate HIP streams (step_overlapped)
     hipStream_t lane_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -78,7 +84,6 @@ struct kws_model {
     size_t pipe_groups = 0;
     int* pipe_error_host = nullptr;  // mapped pinned flag the kernel raises if a wait times out
     int* pipe_error_dev = nullptr;
-    size_t scratch_bytes = 0;
     // profiling
     bool profiling = false;
     struct Pending { int slot; hipEvent_t a, b; };
@@ -216,7 +221,10 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
     kws_model* m = new (std::nothrow) kws_model();
     if (!m) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
     m->cfg = *cfg;
-    KWS_HIP(hipGetDevice(&m->device));
+    {
+        const hipError_t e = hipGetDevice(&m->device);
+        if (e != hipSuccess) { delete m; return hip_fail(e, "hipGetDevice"); }
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, m->device) == hipSuccess) m->num_cus = prop.multiProcessorCount;
@@ -418,8 +426,11 @@ int kws_destroy(kws_handle h) {
     for (auto& pd : h->pending) { hipEventDestroy(pd.a); hipEventDestroy(pd.b); }
     for (auto ev : h->event_pool) hipEventDestroy(ev);
     if (h->d_weights) hipFree(h->d_weights);
-    for (int i = 0; i < 8; ++i) if (h->scratch[i]) hipFree(h->scratch[i]);
+    if (h->arena.base) hipFree(h->arena.base);
+    if (h->arena_fine.base) hipFree(h->arena_fine.base);
     if (h->pipe_ready) hipFree(h->pipe_ready);
+    // a layer-pipelined step that timed out and was never followed by another call is still reported, once
+    const bool pipe_failed = h->pipe_error_host && *reinterpret_cast<volatile int*>(h->pipe_error_host) != 0;
     if (h->pipe_error_host) hipHostFree(h->pipe_error_host);
     for (auto ev : h->ovl_events) hipEventDestroy(ev);
     for (auto ev : h->ovl_tail) if (ev) hipEventDestroy(ev);
@@ -428,6 +439,8 @@ int kws_destroy(kws_handle h) {
     if (h->oct_range) hipFree(h->oct_range);
     if (h->oct_prev) hipFree(h->oct_prev);
     delete h;
+    if (pipe_failed)
+        return fail(KWS_ERR_HIP, "the last layer-pipelined step of this handle timed out waiting for the layer below; its results were invalid");
     return KWS_OK;
 }
 
@@ -450,9 +463,6 @@ static bool pipeline_eligible(kws_handle h, int B) {
     // AUTO keeps the resident kernels where they exist even when this launch would be faster (H=128, L=2: +10 % at
     // B <= 2048; L=4, B=1024: 2.2x; select it with KWS_KERNEL_GENERIC): the two kernel families round differently in
     // the last bit, and a stream's result must not depend on how many neighbours it is batched or sharded with.
-#ifdef KWS_NO_PIPELINE
-    return false;
-#endif
     if (h->pipe_disabled) return false;
     if (h->cfg.precision != KWS_FP32 || h->cfg.num_layers < 2 || h->kernel_kind == KWS_KERNEL_RESIDENT) return false;
     for (const auto& L : h->layers)
@@ -461,7 +471,79 @@ static bool pipeline_eligible(kws_handle h, int B) {
     return h->num_cus > 0 && groups * h->cfg.num_layers <= h->num_cus;
 }
 
-static int ensure_scratch(kws_handle h, int B, int T) {
+// ---- scratch: what a call of shape (B, T) needs, and the arena it is carved from ------------------------------------
+#ifndef KWS_OVERLAP_MIN_T
+#define KWS_OVERLAP_MIN_T 64
+#endif
+static bool overlap_shape_ok(kws_handle h, int B, int T) {      // step_overlapped, leaving the profiling switch aside
+    const kws_config& c = h->cfg;
+    if (c.precision != KWS_FP32 || c.num_layers < 2 || c.num_layers > 5) return false;
+    if (pipeline_eligible(h, B)) return false;            // the streaming kernel has its own in-kernel pipeline
+    const long long groups = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
+    return h->num_cus > 0 && groups * c.num_layers <= h->num_cus && T >= KWS_OVERLAP_MIN_T;
+}
+static bool overlap_eligible(kws_handle h, int B, int T) { return !h->profiling && overlap_shape_ok(h, B, T); }
+static void overlap_blocks(int T, int* nb_out, int* tb_out) {
+    int nb = T / 32 < 8 ? T / 32 : 8;              // more blocks: less fill/drain, more launch prologues (8: +6 % over 4)
+    if (nb < 2) nb = 2;
+    const int Tb = ((T + nb - 1) / nb + 15) & ~15;        // multiple of the epilogue ring
+    *nb_out = (T + Tb - 1) / Tb;
+    *tb_out = Tb;
+}
+
+struct SeamLayout { int nbuf; size_t bytes_each; bool fine; };
+constexpr int kNoFineGrainedMemory = 1;      // carve_seams: internal, never returned through the ABI
+enum { kLayoutSequential = 0, kLayoutOverlapped = 1 };
+static SeamLayout seam_layout(kws_handle h, int B, int T, int which) {
+    const kws_config& c = h->cfg;
+    const size_t groups = (size_t)(B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
+    const size_t frame_bytes = groups * (size_t)c.hidden * 16 * sizeof(float);
+    SeamLayout s = {0, 0, false};
+    if (c.precision == KWS_BF16 || T <= 0 || B <= 0) return s;                    // the bf16 stack has no seam
+    const bool int8 = c.precision == KWS_INT8;
+    if (c.num_layers < 2 && !int8) return s;
+    if (which == kLayoutOverlapped) {
+        int nb, Tb;
+        overlap_blocks(T, &nb, &Tb);
+        s.nbuf = 2 * (c.num_layers - 1); s.bytes_each = frame_bytes * Tb;
+        return s;
+    }
+    if (pipeline_eligible(h, B)) { s.nbuf = c.num_layers - 1; s.bytes_each = frame_bytes * T; s.fine = true; return s; }
+    s.nbuf = (c.num_layers > 2 || int8) ? 2 : 1;         // sequential launches ping-pong two buffers
+    s.bytes_each = frame_bytes * T;
+    return s;
+}
+
+// Grows the arena if this layout does not fit (the only place kws_step can synchronise: the old block may still be in
+// use) and points h->scratch[] at the call's buffers.
+static int carve_seams(kws_handle h, const SeamLayout& want) {
+    SeamLayout s = want;
+    s.bytes_each = (s.bytes_each + 255) & ~size_t(255);
+    kws_model::Arena& A = s.fine ? h->arena_fine : h->arena;
+    const size_t need = (size_t)s.nbuf * s.bytes_each;
+    if (need > A.bytes) {
+        KWS_HIP(hipDeviceSynchronize());
+        if (A.base) { hipFree(A.base); A.base = nullptr; A.bytes = 0; }
+        hipError_t e;
+        // pipelined seams are read by another XCD while the kernel runs: fine-grained (uncached, coherent) memory
+        if (s.fine) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&A.base), need, hipDeviceMallocFinegrained);
+        else e = hipMalloc(reinterpret_cast<void**>(&A.base), need);
+        if (e != hipSuccess) {
+            A.base = nullptr;
+            (void)hipGetLastError();
+            return s.fine ? kNoFineGrainedMemory : hip_fail(e, "hipMalloc(scratch)");
+        }
+        A.bytes = need;
+        ++h->scratch_allocs;
+    }
+    for (int i = 0; i < 8; ++i)
+        h->scratch[i] = i < s.nbuf ? reinterpret_cast<float4*>(A.base + (size_t)i * s.bytes_each) : nullptr;
+    h->nscratch = s.nbuf;
+    return KWS_OK;
+}
+
+// Everything besides the seams that depends on the batch size: int8 exchange buffers, the pipelined launch's counters.
+static int ensure_side_buffers(kws_handle h, int B) {
     const size_t groups = (size_t)(B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
     if (h->cfg.precision == KWS_INT8 && groups > h->oct_groups) {
         KWS_HIP(hipDeviceSynchronize());
@@ -473,42 +555,77 @@ static int ensure_scratch(kws_handle h, int B, int T) {
         KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->oct_range), groups * 16 * sizeof(float2)));
         KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->oct_prev), groups * 16 * sizeof(int32_t)));
         h->oct_groups = groups;
+        ++h->scratch_allocs;
     }
-    if (h->cfg.num_layers < 2 && h->cfg.precision != KWS_INT8) return KWS_OK;
-    const size_t bytes = groups * (size_t)T * h->cfg.hidden * 16 * sizeof(float);
-    const int want_bufs = pipeline_eligible(h, B) ? h->cfg.num_layers - 1 : 0;
-    if (bytes <= h->scratch_bytes && want_bufs <= h->nscratch && (want_bufs == 0 || h->scratch_fine)) return KWS_OK;
-    KWS_HIP(hipDeviceSynchronize());
-    for (int i = 0; i < 8; ++i) if (h->scratch[i]) { hipFree(h->scratch[i]); h->scratch[i] = nullptr; }
-    h->scratch_bytes = 0;
-    // sequential launches ping-pong two buffers; the layer-pipelined launch has every seam live at once
-    int nbuf = (h->cfg.num_layers > 2 || h->cfg.precision == KWS_INT8) ? 2 : 1;
-    const bool fine = pipeline_eligible(h, B);
-    if (fine) nbuf = h->cfg.num_layers - 1;
-    // pipelined seams are read by another XCD while the kernel runs: fine-grained (uncached, coherent) memory
-    for (int i = 0; i < nbuf; ++i) {
-        if (fine) {
-            if (hipExtMallocWithFlags(reinterpret_cast<void**>(&h->scratch[i]), bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-                // no fine-grained device memory on this system: give the pipelined launch up for this handle
+    if (pipeline_eligible(h, B)) {
+        if (!h->pipe_error_host) {
+            KWS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pipe_error_host), sizeof(int), hipHostMallocMapped));
+            *h->pipe_error_host = 0;
+            KWS_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pipe_error_dev), h->pipe_error_host, 0));
+        }
+        if (groups > h->pipe_groups) {
+            KWS_HIP(hipDeviceSynchronize());
+            if (h->pipe_ready) hipFree(h->pipe_ready);
+            h->pipe_ready = nullptr; h->pipe_groups = 0;
+            if (hipExtMallocWithFlags(reinterpret_cast<void**>(&h->pipe_ready), (size_t)h->cfg.num_layers * groups * sizeof(int),
+                                      hipDeviceMallocFinegrained) != hipSuccess) {
                 (void)hipGetLastError();
-                for (int k = 0; k < i; ++k) { hipFree(h->scratch[k]); h->scratch[k] = nullptr; }
-                h->pipe_disabled = true;
-                return ensure_scratch(h, B, T);
+                h->pipe_ready = nullptr;
+                h->pipe_disabled = true;         // no fine-grained device memory here: layer-by-layer launches from now on
+                return KWS_OK;
             }
-        } else {
-            KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
+            h->pipe_groups = groups;
+            ++h->scratch_allocs;
         }
     }
-    h->scratch_fine = fine;
-    h->nscratch = nbuf;
-    h->scratch_bytes = bytes;
     return KWS_OK;
+}
+
+// Seams of the sequential / pipelined layout for a call of shape (B, T).
+static int ensure_scratch(kws_handle h, int B, int T) {
+    int rc = ensure_side_buffers(h, B);
+    if (rc != KWS_OK) return rc;
+    rc = carve_seams(h, seam_layout(h, B, T, kLayoutSequential));
+    if (rc == kNoFineGrainedMemory) {    // fine-grained memory unavailable: give the pipelined launch up for this handle
+        h->pipe_disabled = true;
+        rc = carve_seams(h, seam_layout(h, B, T, kLayoutSequential));
+    }
+    return rc;
 }
 
 int kws_reserve(kws_handle h, int B, int T) {
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
     if (B < 0 || T < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative B=%d or T=%d", B, T);
-    return ensure_scratch(h, B, T);
+    // whichever launch layout kws_step picks for (B, T) -- it depends on kws_set_profiling too -- fits afterwards
+    int rc = ensure_scratch(h, B, T);
+    if (rc != KWS_OK) return rc;
+    if (overlap_shape_ok(h, B, T)) rc = carve_seams(h, seam_layout(h, B, T, kLayoutOverlapped));
+    return rc;
+}
+
+int kws_scratch_stats(kws_handle h, size_t* bytes_reserved, int32_t* allocations) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (bytes_reserved) *bytes_reserved = h->arena.bytes + h->arena_fine.bytes;
+    if (allocations) *allocations = h->scratch_allocs;
+    return KWS_OK;
+}
+
+// A layer-pipelined launch whose wait for the layer below timed out raises a mapped host flag; its results are invalid.
+// The flag is looked at (without synchronising) on every kws_step, by kws_poll_error, after the event syncs of
+// kws_kernel_times and in kws_destroy -- a step's own flag can only be seen once its kernel has run, so a caller that
+// needs certainty synchronises the stream and asks kws_poll_error.
+static int check_pipe_error(kws_handle h) {
+    if (h->pipe_error_host && *reinterpret_cast<volatile int*>(h->pipe_error_host)) {
+        *reinterpret_cast<volatile int*>(h->pipe_error_host) = 0;
+        h->pipe_disabled = true;             // later steps launch layer by layer
+        return fail(KWS_ERR_HIP, "a layer-pipelined launch timed out waiting for the layer below; the results of that step are invalid");
+    }
+    return KWS_OK;
+}
+
+int kws_poll_error(kws_handle h) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    return check_pipe_error(h);
 }
 
 int kws_set_profiling(kws_handle h, int enable) {
@@ -537,7 +654,7 @@ int kws_kernel_times(kws_handle h, float* ms_sum, int32_t* launches, int reset) 
         std::fill(h->ms_sum.begin(), h->ms_sum.end(), 0.f);
         std::fill(h->launches.begin(), h->launches.end(), 0);
     }
-    return KWS_OK;
+    return check_pipe_error(h);
 }
 
 // Layers on separate HIP streams, time-blocked.  When L x groups workgroups fit the chip at once, the layers of a
@@ -546,35 +663,16 @@ int kws_kernel_times(kws_handle h, float* ms_sum, int32_t* launches, int reset) 
 // The kernels are the ones a plain call uses -- a call on frames [t0, t1) with the state carried is bit-identical to
 // the corresponding slice of one long call (tests/test_gpu_parity.py) -- so the result does not depend on whether
 // this path was taken.  Wall time ~ (slowest layer) x (1 + 1/blocks) instead of the sum over layers.
-#ifndef KWS_OVERLAP_MIN_T
-#define KWS_OVERLAP_MIN_T 64
-#endif
-static bool overlap_eligible(kws_handle h, int B, int T) {
-    const kws_config& c = h->cfg;
-    if (c.precision != KWS_FP32 || c.num_layers < 2 || c.num_layers > 5 || h->profiling) return false;
-    if (pipeline_eligible(h, B)) return false;            // the streaming kernel has its own in-kernel pipeline
-    const long long groups = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
-    return h->num_cus > 0 && groups * c.num_layers <= h->num_cus && T >= KWS_OVERLAP_MIN_T;
-}
-
 static int step_overlapped(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
                            float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
                            int32_t* prev_word, float decode2_thres, int B, int T, hipStream_t st) {
     const kws_config& c = h->cfg;
     const int H = c.hidden, L = c.num_layers, C = c.num_classes;
-    int nb = T / 32 < 8 ? T / 32 : 8;              // more blocks: less fill/drain, more launch prologues (8: +6 % over 4)
-    if (nb < 2) nb = 2;
-    const int Tb = ((T + nb - 1) / nb + 15) & ~15;        // multiple of the epilogue ring
-    nb = (T + Tb - 1) / Tb;
-    const size_t groups = (size_t)(B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
-    const size_t bytes = groups * (size_t)Tb * H * 16 * sizeof(float);
-    const int nbuf = 2 * (L - 1);
-    if (bytes > h->scratch_bytes || h->nscratch < nbuf || h->scratch_fine) {
-        KWS_HIP(hipDeviceSynchronize());
-        for (int i = 0; i < 8; ++i) if (h->scratch[i]) { hipFree(h->scratch[i]); h->scratch[i] = nullptr; }
-        h->scratch_bytes = 0; h->nscratch = 0; h->scratch_fine = false;
-        for (int i = 0; i < nbuf; ++i) KWS_HIP(hipMalloc(reinterpret_cast<void**>(&h->scratch[i]), bytes));
-        h->nscratch = nbuf; h->scratch_bytes = bytes;
+    int nb, Tb;
+    overlap_blocks(T, &nb, &Tb);
+    {
+        const int rc = carve_seams(h, seam_layout(h, B, T, kLayoutOverlapped));
+        if (rc != KWS_OK) return rc;
     }
     for (int l = 1; l < L; ++l)
         if (!h->lane_stream[l]) KWS_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
@@ -645,6 +743,10 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     hipStream_t st = static_cast<hipStream_t>(stream);
     const kws_config& c = h->cfg;
     const int H = c.hidden, L = c.num_layers;
+    {
+        const int rc = check_pipe_error(h);      // raised by an earlier layer-pipelined step of this handle
+        if (rc != KWS_OK) return rc;
+    }
     if (h->ovl_tail_valid) {
         // the previous call ran its upper layers on the handle's own streams: whatever stream this call comes in on,
         // it must not touch the seam buffers (or reallocate them) before those kernels are done
@@ -705,29 +807,9 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     const int groups = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
     kws::GruStackParams sp;
     if (pipelined) {
-        if (h->pipe_error_host && *reinterpret_cast<volatile int*>(h->pipe_error_host)) {
-            *reinterpret_cast<volatile int*>(h->pipe_error_host) = 0;
-            h->pipe_disabled = true;             // later steps launch layer by layer
-            return fail(KWS_ERR_HIP, "a layer-pipelined launch timed out waiting for the layer below; the previous step's results are invalid");
-        }
-        if (!h->pipe_error_host) {
-            KWS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->pipe_error_host), sizeof(int), hipHostMallocMapped));
-            *h->pipe_error_host = 0;
-            KWS_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pipe_error_dev), h->pipe_error_host, 0));
-        }
-        if ((size_t)groups > h->pipe_groups) {
-            KWS_HIP(hipDeviceSynchronize());
-            if (h->pipe_ready) hipFree(h->pipe_ready);
-            h->pipe_ready = nullptr; h->pipe_groups = 0;
-            KWS_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&h->pipe_ready), (size_t)L * groups * sizeof(int), hipDeviceMallocFinegrained));   // seams were allocated the same way a moment ago
-            h->pipe_groups = groups;
-        }
         KWS_HIP(hipMemsetAsync(h->pipe_ready, 0, (size_t)L * h->pipe_groups * sizeof(int), st));
         memset(&sp, 0, sizeof(sp));
         sp.L = L; sp.G = groups; sp.xcd_affine = (8 % L == 0) ? 1 : 0;
-#ifdef KWS_PIPE_NOAFFINITY
-        sp.xcd_affine = 0;
-#endif
     }
     for (int l = 0; l < L; ++l) {
         const LayerDev& Ld = h->layers[l];
@@ -762,12 +844,6 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         p.B = B; p.T = T; p.I = Ld.in_dim; p.C = c.num_classes;
         p.KCX = resident ? Ld.kcx_res : Ld.kcx_gen;
 
-#ifdef KWS_TIMING
-        static unsigned long long* dbg_buf[8] = {nullptr};
-        const int groups_ = (B + 15) / 16;
-        if (!dbg_buf[l]) hipMalloc(reinterpret_cast<void**>(&dbg_buf[l]), (size_t)4096 * 4 * 8 * 8 * 2);
-        p.dbg = groups_ <= 4096 ? dbg_buf[l] : nullptr;
-#endif
         if (pipelined) {
             p.ready_in = first ? nullptr : h->pipe_ready + (size_t)(l - 1) * h->pipe_groups;
             p.ready_out = last ? nullptr : h->pipe_ready + (size_t)l * h->pipe_groups;
@@ -800,31 +876,8 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             op.seq_len = seq_len; op.reset = reset_mask;
             op.aq = h->oct_aq; op.B = B; op.T = T;
             op.range = (l == L - 1) ? h->oct_range : nullptr;
-#ifdef KWS_TIMING
-            static unsigned long long* odbg = nullptr;
-            if (!odbg) hipMalloc(reinterpret_cast<void**>(&odbg), (size_t)4096 * 8 * 12 * 8);
-            op.dbg = (B + 15) / 16 <= 4096 ? odbg : nullptr;
-#endif
             e = kws::launch_gru_layer_octbit(op, st);
             if (e != hipSuccess) return hip_fail(e, "launch gru_layer_octbit");
-#ifdef KWS_TIMING
-            {
-                static int dumped = 0;
-                if (op.dbg && h->profiling && dumped++ == 2) {
-                    hipDeviceSynchronize();
-                    std::vector<unsigned long long> hb((size_t)4096 * 8 * 12);
-                    hipMemcpy(hb.data(), op.dbg, hb.size() * 8, hipMemcpyDeviceToHost);
-                    static const char* nm[12] = {"quant0", "sync+inv", "dotA", "bar", "finA", "bar", "quant1", "sync+inv", "dotB", "bar", "finB", "bar"};
-                    for (int gi : {0, 100}) for (int wv : {0, 5}) {
-                        if (gi >= (B + 15) / 16) continue;
-                        fprintf(stderr, "OCT TIMING group %d wave %d per-frame cycles:", gi, wv);
-                        double tot = 0;
-                        for (int i = 0; i < 12; ++i) { const double v = (double)hb[((size_t)gi * 8 + wv) * 12 + i] / T; tot += v; fprintf(stderr, " %s %.0f", nm[i], v); }
-                        fprintf(stderr, " | total %.0f\n", tot);
-                    }
-                }
-            }
-#endif
         } else {
             e = resident ? kws::launch_gru_layer_resident(p, first, last, st)
                          : kws::launch_gru_layer_generic(p, H, first, last, st);
@@ -851,28 +904,6 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             KWS_HIP(hipEventRecord(eb, st));
             h->pending.push_back({l, ea, eb});
         }
-#ifdef KWS_TIMING
-        {
-            static int dumped[8] = {0};
-            if (p.dbg && h->profiling && dumped[l]++ == 2) {
-                hipDeviceSynchronize();
-                std::vector<unsigned long long> hb((size_t)4096 * 4 * 8 * 2);
-                hipMemcpy(hb.data(), p.dbg, hb.size() * 8, hipMemcpyDeviceToHost);
-                for (int gi : {0, 1, 100, 255}) {
-                    if (gi >= groups_) continue;
-                    for (int wv = 0; wv < 4; ++wv) {
-                        const unsigned long long* d = &hb[((size_t)gi * 4 + wv) * 8];
-                        const double T_ = (double)d[5];
-                        fprintf(stderr, "TIMING layer %d group %3d wave %d: per-frame cycles  seg1 %.0f wait1 %.0f seg2 %.0f wait2 %.0f total %.0f\n",
-                                l, gi, wv, d[0] / T_, d[1] / T_, d[2] / T_, d[3] / T_, d[4] / T_);
-                        const unsigned long long* f = &hb[(size_t)4096 * 4 * 8 + ((size_t)gi * 4 + wv) * 8];
-                        fprintf(stderr, "  FINE post-B2 %.0f | gates_h %.0f | regionA %.0f | B1 %.0f | gx2 %.0f | cand_h %.0f | regionB %.0f\n",
-                                f[0] / T_, f[1] / T_, f[2] / T_, f[3] / T_, f[4] / T_, f[5] / T_, f[6] / T_);
-                    }
-                }
-            }
-        }
-#endif
     }
     return KWS_OK;
 }
@@ -882,6 +913,11 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres,
     *out = nullptr;
     if (B < 1 || max_chunks < 1 || max_frames < 1 || C < 3 || C > 64)
         return fail(KWS_ERR_INVALID_ARGUMENT, "bad window shape B=%d chunks=%d frames=%d C=%d", B, max_chunks, max_frames, C);
+    // window_step_kernel: one lane per queued chunk (wave-wide prefix scan) and three byte images of the window in LDS
+    if (max_chunks > 64)
+        return fail(KWS_ERR_UNSUPPORTED, "max_chunks=%d unsupported (1..64; the reference uses SimpleQueue(15), detector.py:122)", max_chunks);
+    if ((size_t)3 * max_chunks * ((max_frames + 15) & ~15) > 64 * 1024)
+        return fail(KWS_ERR_UNSUPPORTED, "window of %d chunks x %d frames exceeds the 64 KiB of LDS the kernel stages it in", max_chunks, max_frames);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(KWS_ERR_NO_DEVICE, "no HIP device visible");
     kws_window* wnd = new (std::nothrow) kws_window();

@@ -3,12 +3,35 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "kws_amd.h"
 
 namespace kws {
 
 constexpr int kStreamsPerGroup = 16;  // MFMA N dimension: one workgroup advances 16 streams
 constexpr int kMaxClasses = 8;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: one process may drive several GPUs
+// (one handle each) from several host threads, so the "already granted" cache is per (kernel instantiation, device)
+// and atomic.  Setting the attribute twice is harmless; skipping it on a second device makes the launch fail there.
+constexpr int kMaxDevices = 64;
+struct LdsGrant { std::atomic<size_t> bytes[kMaxDevices]; };
+template <typename K>
+inline hipError_t grant_dynamic_lds(K kernel, LdsGrant& cache, size_t lds) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool cached = dev >= 0 && dev < kMaxDevices;
+    if (cached && cache.bytes[dev].load(std::memory_order_acquire) >= lds) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (cached) {
+        size_t seen = cache.bytes[dev].load(std::memory_order_relaxed);
+        while (seen < lds && !cache.bytes[dev].compare_exchange_weak(seen, lds, std::memory_order_release)) {}
+    }
+    return hipSuccess;
+}
 
 // One launch = one GRU layer over all T frames of the call, for every 16-stream group.
 //
@@ -43,7 +66,6 @@ struct GruLayerParams {
     int t_stride;           // frames per stream row of x_mel / logits / softmax / tokens (0: T) -- a call on a time block
     int t_base;             // of a longer sequence passes pre-offset pointers, the full row stride, and its first frame
     int KCX;                // x-part k-chunks (generic: multiple of 4)
-    unsigned long long* dbg;  // timing-variant builds only (tools/build_variant.sh -DKWS_TIMING)
     // layer-pipelined launch (generic kernel): frames published by the layer below / by this layer, per group
     const int* ready_in;
     int* ready_out;
@@ -89,7 +111,6 @@ struct GruOctbitParams {
     uint32_t* aq;           // activation exchange [G][2][16 streams][128 dwords]
     float2* range;          // top layer only: (min, max) of each stream's emitted rows, for the projection; else null
     int B, T;
-    unsigned long long* dbg;  // timing-variant builds only (-DKWS_TIMING)
 };
 struct OctbitFcParams {
     const uint32_t* wfc;    // [8 tiles][4 g][kMaxClasses][even,odd] int16 pairs

@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
             if (row[c] > best) { best = row[c]; arg = c - 1; }
         gring[slot * TM + t] = (int8_t)(best > p.thres ? arg : -1);
     }
-    // chunk lengths in FIFO order: lane q holds chunk q, then an exclusive prefix over the <= 15 lanes
+    // chunk lengths in FIFO order: lane q holds chunk q (NQ <= 64, checked by kws_window_create), then an inclusive
+    // prefix over the whole wave
     int len = 0;
     if (lane < count) {
         const int sl = (head + lane) % NQ;
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
     }
     int incl = len;
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
+    for (int d = 1; d < 64; d <<= 1) {
         const int v = __shfl_up(incl, d);
         if (lane >= d) incl += v;
     }

@@ -83,6 +83,16 @@ class DeployModel(object):
     def reserve(self, batch, frames):
         _lib.check(self._lib.kws_reserve(self._handle, int(batch), int(frames)))
 
+    def scratch_stats(self):
+        """(bytes reserved for inter-layer seams, device (re)allocations so far -- each one synchronised)."""
+        nbytes, allocs = ctypes.c_size_t(), ctypes.c_int32()
+        _lib.check(self._lib.kws_scratch_stats(self._handle, ctypes.byref(nbytes), ctypes.byref(allocs)))
+        return int(nbytes.value), int(allocs.value)
+
+    def status(self):
+        """Raises if a finished asynchronous step of this handle failed on the device (kws_poll_error)."""
+        _lib.check(self._lib.kws_poll_error(self._handle))
+
     def set_profiling(self, enable):
         _lib.check(self._lib.kws_set_profiling(self._handle, int(bool(enable))))
 

@@ -41,3 +41,13 @@ def reduce_throughput(dist, frames, seconds, device):
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(s, op=dist.ReduceOp.MAX)
     return int(round(f.item())), float(s.item())
+
+
+def count_ranks(dist, device):
+    """all-reduce(SUM) of 1: how many ranks actually took part in the report (the bench line's `ranks_seen`)."""
+    import torch
+    if dist is None or not dist.is_initialized():
+        return 1
+    one = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())

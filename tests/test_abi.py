@@ -95,3 +95,17 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "kws_oracle" not in text, f
+
+
+def test_window_shape_limits_are_rejected_before_any_device_work():
+    """kws_window_create: one lane per queued chunk (<= 64) and the window staged in <= 64 KiB of LDS."""
+    from keyword_spotting_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.kws_window_create(4, 65, 32, 6, 0.4, ctypes.byref(h)) == _lib.KWS_ERR_UNSUPPORTED
+    assert b"max_chunks=65" in lib.kws_last_error()
+    assert lib.kws_window_create(4, 64, 512, 6, 0.4, ctypes.byref(h)) == _lib.KWS_ERR_UNSUPPORTED
+    assert b"LDS" in lib.kws_last_error()
+    assert lib.kws_window_create(4, 0, 32, 6, 0.4, ctypes.byref(h)) == _lib.KWS_ERR_INVALID_ARGUMENT
+    if not have_gpu():
+        assert lib.kws_window_create(4, 64, 32, 6, 0.4, ctypes.byref(h)) == _lib.KWS_ERR_NO_DEVICE

@@ -57,3 +57,48 @@ def test_two_rank_sharding_equals_unsharded(tmp_path):
 def test_single_process_reduce_is_identity():
     from keyword_spotting_amd import sharding
     assert sharding.reduce_throughput(None, 1200, 0.5, torch.device("cpu")) == (1200, 0.5)
+
+
+def _run_stub_bench(args, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable] + args, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                           # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_main_two_ranks_over_gloo_prints_one_line():
+    """bench.py's own launcher + N>1 path (what the driver runs with --gpus N on an 8-GPU node), model stubbed at the
+    DeployModel boundary: self-launch through torch.distributed.run, both ranks counted, frames summed over ranks,
+    time = the slower rank's."""
+    stub = os.path.join("tests", "bench_stub_main.py")
+    line = _run_stub_bench([stub, "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "64", "--frames", "10",
+                            "--dist-backend", "gloo"])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    assert line["steps"] == 6 and line["warmup"] == 2 and line["unit"] == "mel-frames/s"
+    assert line["config"]["parallelism"] == "utterance-dp2"
+    # rank 1 sleeps 20 ms per step: 6 steps >= 120 ms; both ranks' frames are counted
+    assert line["ms_per_step"] >= 19.0
+    assert abs(line["value"] - 2 * 64 * 10 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-6 * line["value"]
+    assert "cpu_baseline" not in line                           # rank 0 at N=1 only
+
+
+def test_bench_main_under_an_external_torchrun_and_single_rank():
+    """The driver's own form: python -m torch.distributed.run ... bench.py --gpus N (RANK/WORLD_SIZE from the env)."""
+    import sys
+    stub = os.path.join("tests", "bench_stub_main.py")
+    line = _run_stub_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(_free_port()), stub, "--gpus", "2", "--steps", "3",
+                            "--warmup", "1", "--batch", "32", "--frames", "8", "--dist-backend", "gloo"])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    one = _run_stub_bench([stub, "--steps", "3", "--warmup", "1", "--batch", "32", "--frames", "8", "--dist-backend", "gloo"])
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert abs(one["value"] - 32 * 8 * 3 / (one["ms_per_step"] * 3e-3)) < 1e-6 * one["value"]

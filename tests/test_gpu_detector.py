@@ -136,3 +136,71 @@ def test_stream_manager_equals_host_detector():
             total += int(want.sum())
             pos += n
         assert total > 0 or label == "1233"
+
+
+@pytest.mark.parametrize("window_chunks", [1, 16, 17, 40, 64])
+def test_stream_manager_window_sizes_beyond_the_reference_default(window_chunks):
+    """The window kernel holds one queued chunk per lane: every size up to 64 chunks must behave like the host
+    SimpleQueue loop, in particular 17..64 (a 16-lane prefix scan once mis-concatenated those)."""
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.detector import HotwordDetector, StreamManager
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    w = _keyword_weights(seed=7)
+    b = 9
+    nchunks = min(90, 2 * window_chunks + 12)
+    mel = torch.from_numpy(G.synthetic_mel(b, 8 * nchunks, 40, seed=97)).cuda()
+    cfg = get_config()
+    # a label that random weights never spell keeps the window full, so eviction at `window_chunks` is exercised;
+    # the decisions compared are then made on the longest possible concatenation
+    for label in ("1233", "21"):
+        det = HotwordDetector(DeployModel(cfg, w), batch=b, window_chunks=window_chunks, label=label)
+        mgr = StreamManager(DeployModel(cfg, w), batch=b, window_chunks=window_chunks, max_frames=8, label=label)
+        for ci in range(nchunks):
+            x = mel[:, 8 * ci:8 * (ci + 1)].contiguous()
+            want = np.zeros(b, np.int32)
+            want[det.feed(x)] = 1
+            got = mgr.feed(x).cpu().numpy()
+            np.testing.assert_array_equal(got, want, err_msg="window %d label %s chunk %d" % (window_chunks, label, ci))
+
+
+@pytest.mark.parametrize("window_chunks,frames", [(15, 23), (17, 5), (33, 16), (64, 7)])
+def test_window_kernel_against_the_oracle_queue(window_chunks, frames):
+    """kws_window_step alone, fed planted one-word-per-chunk softmax: SimpleQueue(max) + concatenate + ctc_decode2 +
+    ctc_predict replayed with the oracle, per stream, over enough steps that windows fill, evict, clear and restart."""
+    import ctypes
+    from keyword_spotting_amd import _lib
+    lib = _lib.load()
+    b, steps, label = 12, 260, "2312"
+    rng = np.random.default_rng(1000 + window_chunks)
+    win = ctypes.c_void_p()
+    _lib.check(lib.kws_window_create(b, window_chunks, frames, 6, 0.4, ctypes.byref(win)))
+    queues = [D.SimpleQueue(window_chunks) for _ in range(b)]
+    hit = torch.zeros(b, dtype=torch.int32, device="cuda")
+    restart = torch.zeros(b, dtype=torch.uint8, device="cuda")
+    fired = 0
+    for step in range(steps):
+        t = int(rng.integers(1, frames + 1))
+        word = rng.integers(-1, 4, size=(b, 1))                            # one word (or none) per chunk and stream
+        sm = np.full((b, t, 6), 0.02, np.float32)
+        for s in range(b):
+            if word[s, 0] >= 0:
+                sm[s, :, 1 + word[s, 0]] = 0.9
+            else:
+                sm[s, :, 5] = 0.9
+        clear = (rng.random(b) < 0.01).astype(np.uint8)
+        sm_d = torch.from_numpy(sm).cuda()
+        _lib.check(lib.kws_window_step(win, _lib.ptr(sm_d), t, _lib.ptr(torch.from_numpy(clear).cuda()), label.encode(),
+                                       _lib.ptr(hit), _lib.ptr(restart), _lib.current_stream_ptr()))
+        got = hit.cpu().numpy()
+        assert np.array_equal(restart.cpu().numpy(), got.astype(np.uint8))
+        for s in range(b):
+            if clear[s]:
+                queues[s].clear()
+            queues[s].add(sm[s])
+            want = D.ctc_predict(D.ctc_decode2(np.concatenate(queues[s].get_all(), 0), 6, 0.4), label)
+            assert int(got[s]) == int(want), (step, s)
+            if want:
+                queues[s].clear()
+                fired += 1
+    assert fired >= 3
+    lib.kws_window_destroy(win)

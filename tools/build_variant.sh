@@ -1,10 +1,21 @@
 #!/bin/bash
-# tools/build_variant.sh <name> [-DFLAG ...]  -> gpurun_variants/libkws_<name>.so (timing experiments)
+# tools/build_variant.sh <name> [--patch tools/patches/<x>.patch ...] [-DFLAG ...]  ->  variants/libkws_<name>.so
+# Experiment builds (timing instrumentation, ablations) are made from a patched COPY of the sources, so the product
+# sources carry no experiment code.  tools/patches/timing_ablation.patch re-adds the s_memtime phase counters
+# (-DKWS_TIMING) and the KWS_ABL_* ablation switches as they were at the end of round 1 (it applies to that
+# revision of the kernels; refresh it when the frame loop changes).  Load the result with KWS_AMD_LIB=variants/libkws_<name>.so.
 set -e
 NAME=$1; shift
 ROOT=$(cd $(dirname $0)/.. && pwd)
 OUT=$ROOT/variants; mkdir -p $OUT
-C=$ROOT/keyword_spotting_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$ROOT/include -I$C -Wno-unused-value -Wno-unused-result "$@" \
-  $C/gru_kernels.hip $C/gru_bf16.hip $C/gru_octbit.hip $C/frontend_kernels.hip $C/stream_kernels.hip $C/decode_kernels.hip $C/octbit_kernels.hip $C/kws_api.hip -o $OUT/libkws_$NAME.so
+W=$(mktemp -d)
+mkdir -p $W/keyword_spotting_amd && cp -r $ROOT/keyword_spotting_amd/csrc $W/keyword_spotting_amd/csrc && rm -rf $W/keyword_spotting_amd/csrc/_obj
+FLAGS=()
+while [ $# -gt 0 ]; do
+  if [ "$1" == "--patch" ]; then (cd $W && patch -p1 < $(realpath $2)); shift 2; else FLAGS+=("$1"); shift; fi
+done
+C=$W/keyword_spotting_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$ROOT/include -I$C -Wno-unused-value -Wno-unused-result "${FLAGS[@]}" \
+  $C/*.hip -o $OUT/libkws_$NAME.so
+rm -rf $W
 echo built $OUT/libkws_$NAME.so
