@@ -1,0 +1,137 @@
+"""Every BASELINE.json config that fits one GPU, at its FULL size, against the matching oracle.
+
+configs[1] (fp32, B=4096 x T=300) lives in test_gpu_parity.py::test_full_size_properties.  Here:
+  configs[2]  bf16 and int8 ("octbit") variants, B=4096 x T=300
+  configs[4]  4 x GRU h=256, n_mel=60, B=1024 x T=300 (the layer-pipelined launch)
+Each: (i) >= 30 streams sampled across the batch (first/last group, group seams, the middle) compared with the oracle
+that restates that arithmetic -- gru_forward_bf16 / gru_forward_octbit / the C oracle -- with the tolerance the
+small-shape tests of that variant use; (ii) batch-composition independence, bitwise: a stream's result does not depend
+on which neighbours it is batched (or sharded) with; (iii) chunked == one shot where the variant's semantics allow it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gru_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+PICK = [0, 1, 15, 16, 17, 31, 2047, 2048, 2049, 4079, 4080, 4094, 4095] + list(range(100, 4000, 205))   # 33 streams
+
+
+def _mel(b, t, n_mel, seed):
+    rng = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(b, t, n_mel, generator=rng).abs() * 2).cuda()
+
+
+def _model(**kw):
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg = get_config(**{k: v for k, v in kw.items() if k != "weights"})
+    return DeployModel(cfg, kw["weights"])
+
+
+def test_bf16_full_size_against_the_rounding_oracle():
+    assert len(PICK) >= 30
+    w = G.init_weights()
+    b, t = 4096, 300
+    mel = _mel(b, t, 40, 171)
+    m = _model(precision="bf16", weights=w)
+    whole = m.forward(mel, m.zero_state(b))
+    want_l, want_s = G.gru_forward_bf16(w, mel[PICK].cpu().numpy())
+    got_l, got_s = whole["logits"][PICK].cpu().numpy(), whole["state"][:, PICK].cpu().numpy()
+    el, es = np.abs(got_l - want_l), np.abs(got_s - want_s)
+    print("bf16 B=4096 T=300, %d streams vs oracle: logits mean %.2e max %.2e | state mean %.2e max %.2e"
+          % (len(PICK), el.mean(), el.max(), es.mean(), es.max()))
+    # tolerances of test_gpu_bf16.py::test_bf16_matches_rounding_oracle (bf16 tie flips: 2^-8 relative, stationary in T)
+    assert el.max() < 6e-2 and el.mean() < 6e-3 and es.max() < 2e-2 and es.mean() < 1e-3
+    part = m.forward(mel[PICK].contiguous(), m.zero_state(len(PICK)))
+    assert torch.equal(part["logits"], whole["logits"][PICK]) and torch.equal(part["state"], whole["state"][:, PICK])
+    state, pos = m.zero_state(b), 0
+    for n in (150, 22, 128):
+        lg, state = m.step(mel[:, pos:pos + n].contiguous(), state)
+        assert torch.equal(lg, whole["logits"][:, pos:pos + n])
+        pos += n
+    assert torch.equal(state, whole["state"])
+
+
+def test_int8_full_size_against_the_octbit_oracle():
+    w = G.init_weights()
+    b, t = 4096, 300
+    mel = _mel(b, t, 40, 172)
+    m = _model(precision="int8", weights=w)
+    whole = m.forward(mel, m.zero_state(b))
+    want_l, want_s = G.gru_forward_octbit(w, mel[PICK].cpu().numpy())
+    got_l, got_s = whole["logits"][PICK].cpu().numpy(), whole["state"][:, PICK].cpu().numpy()
+    el, es = np.abs(got_l - want_l), np.abs(got_s - want_s)
+    print("int8 B=4096 T=300, %d streams vs oracle: logits mean %.2e max %.2e | state mean %.2e max %.2e"
+          % (len(PICK), el.mean(), el.max(), es.mean(), es.max()))
+    # tolerances of test_gpu_octbit_gru.py::test_int8_matches_oracle (a 1e-7 fp32 difference that crosses a u8
+    # quantiser boundary moves one pre-activation by <= 8.5e-4; rare, does not grow with T)
+    assert el.mean() < 2e-3 and el.max() < 0.1 and es.mean() < 2e-4 and es.max() < 2e-2
+    part = m.forward(mel[PICK].contiguous(), m.zero_state(len(PICK)))
+    assert torch.equal(part["logits"], whole["logits"][PICK]) and torch.equal(part["state"], whole["state"][:, PICK])
+    # the recurrent state is chunking-independent bitwise; the projection's activation range is per call (reference)
+    state, pos = m.zero_state(b), 0
+    for n in (150, 22, 128):
+        _, state = m.step(mel[:, pos:pos + n].contiguous(), state)
+        pos += n
+    assert torch.equal(state, whole["state"])
+
+
+def test_stress_config_full_size_against_the_c_oracle(oracle_c):
+    """configs[4]: L=4, H=256, n_mel=60, B=1024 x T=300 -- 64 groups x 4 layers = one layer-pipelined launch."""
+    w = G.random_weights(60, 256, 4, 6, seed=173)
+    b, t = 1024, 300
+    mel = _mel(b, t, 60, 174)
+    m = _model(n_mel=60, hidden_size=256, num_layers=4, weights=w)
+    whole = m.forward(mel, m.zero_state(b))
+    m.status()
+    pick = [0, 1, 15, 16, 17, 511, 512, 1007, 1008, 1022, 1023] + list(range(40, 1000, 48))
+    assert len(pick) >= 30
+    c_l, _, c_s = oracle_c.gru_forward((60, 256, 4, 6, 0, -1.0), G.weights_to_blob(w), mel[pick].cpu().numpy(),
+                                       np.zeros((4, len(pick), 256), np.float32), threads=8)
+    el = np.abs(whole["logits"][pick].cpu().numpy() - c_l)
+    es = np.abs(whole["state"][:, pick].cpu().numpy() - c_s)
+    print("configs[4] B=1024 T=300, %d streams vs C oracle: logits max %.2e | state max %.2e" % (len(pick), el.max(), es.max()))
+    assert el.max() < 1e-4 and es.max() < 1e-4
+    part = m.forward(mel[pick].contiguous(), m.zero_state(len(pick)))
+    assert torch.equal(part["logits"], whole["logits"][pick]) and torch.equal(part["state"], whole["state"][:, pick])
+    state, pos = m.zero_state(b), 0
+    for n in (150, 22, 128):
+        lg, state = m.step(mel[:, pos:pos + n].contiguous(), state)
+        assert torch.equal(lg, whole["logits"][:, pos:pos + n])
+        pos += n
+    assert torch.equal(state, whole["state"])
+    # 4096 streams of the same model (256 groups x 4 layers > CUs: layer-by-layer launches) agree with the
+    # pipelined launch bit for bit on the shared streams
+    big = torch.cat([mel, _mel(3072, t, 60, 175)], 0)
+    seq = m.forward(big, m.zero_state(4096), want_softmax=False)
+    assert torch.equal(seq["logits"][:b], whole["logits"]) and torch.equal(seq["state"][:, :b], whole["state"])
+
+
+def test_reserved_scratch_is_never_regrown_and_layouts_can_alternate():
+    """kws_reserve sizes the one scratch block for whichever launch layout a shape takes; alternating streaming-hop and
+    long calls (sequential <-> layers overlapped on HIP streams) afterwards neither reallocates nor changes a bit."""
+    w = G.random_weights(40, 128, 3, 6, seed=176)
+    b = 512
+    mel = _mel(b, 300, 40, 177)
+    m = _model(num_layers=3, weights=w)
+    m.reserve(b, 300)
+    nbytes, allocs = m.scratch_stats()
+    assert nbytes > 0 and allocs >= 1
+    ref = _model(num_layers=3, weights=w)
+    sa, sb, pos = m.zero_state(b), ref.zero_state(b), 0
+    for n in (22, 64, 23, 100, 22, 69):                 # 64, 100, 69 frames: overlapped; 22, 23: sequential
+        x = mel[:, pos:pos + n].contiguous()
+        ra = m.forward(x, sa)
+        rb = ref.forward(x, sb)
+        torch.cuda.synchronize()
+        assert torch.equal(ra["logits"], rb["logits"]) and torch.equal(ra["state"], rb["state"])
+        sa, sb, pos = ra["state"], rb["state"], pos + n
+        assert m.scratch_stats() == (nbytes, allocs)
+    m.set_profiling(True)                               # profiling forces sequential launches for the long shapes too
+    r = m.forward(mel[:, :100].contiguous(), m.zero_state(b))
+    assert m.scratch_stats() == (nbytes, allocs)
+    m.kernel_times()
+    one = ref.forward(mel[:, :100].contiguous(), ref.zero_state(b))
+    assert torch.equal(r["logits"], one["logits"])
