@@ -65,17 +65,29 @@ def test_int8_full_size_against_the_octbit_oracle():
     el, es = np.abs(got_l - want_l), np.abs(got_s - want_s)
     print("int8 B=4096 T=300, %d streams vs oracle: logits mean %.2e max %.2e | state mean %.2e max %.2e"
           % (len(PICK), el.mean(), el.max(), es.mean(), es.max()))
-    # tolerances of test_gpu_octbit_gru.py::test_int8_matches_oracle (a 1e-7 fp32 difference that crosses a u8
-    # quantiser boundary moves one pre-activation by <= 8.5e-4; rare, does not grow with T)
-    assert el.mean() < 2e-3 and el.max() < 0.1 and es.mean() < 2e-4 and es.max() < 2e-2
+    # One shot over 300 frames the two implementations drift apart slowly: a 1e-7 fp32 difference (MFMA layer 0,
+    # v_exp/v_rcp) that crosses a u8 quantiser boundary moves one pre-activation by <= 8.5e-4, and a state that is off
+    # by 6e-5 flips ~1 of the 128 codes the projection quantises per frame (one code ~ 1e-2 on a logit).  Measured:
+    # logits mean 1.4e-3 over frames 0..99, 4.6e-3 over frames 200..299.  Loose bound here; the sharp check follows.
+    assert es.mean() < 2e-4 and es.max() < 2e-2 and el.mean() < 6e-3 and el.max() < 0.15
+    # Sharp check at full batch: the same 300 frames in 12 chunks of 25 with the oracle RESTARTED from the GPU's own
+    # state at every chunk boundary, so no difference can compound for more than 25 frames -- every chunk must then
+    # meet the tolerances of the small-shape test (test_gpu_octbit_gru.py::test_int8_matches_oracle).
+    state, pos = m.zero_state(b), 0
+    worst_l, worst_s = 0.0, 0.0
+    for c in range(12):
+        st_in = state[:, PICK].cpu().numpy()
+        r = m.forward(mel[:, pos:pos + 25].contiguous(), state)
+        o_l, o_s = G.gru_forward_octbit(w, mel[PICK, pos:pos + 25].cpu().numpy(), st_in)
+        cl = np.abs(r["logits"][PICK].cpu().numpy() - o_l)
+        cs = np.abs(r["state"][:, PICK].cpu().numpy() - o_s)
+        assert cl.mean() < 2e-3 and cl.max() < 0.1 and cs.mean() < 2e-4 and cs.max() < 2e-2, (c, cl.mean(), cl.max(), cs.mean(), cs.max())
+        worst_l, worst_s = max(worst_l, float(cl.mean())), max(worst_s, float(cs.mean()))
+        state, pos = r["state"], pos + 25
+    print("int8 teacher-forced chunks: worst chunk logits mean %.2e, state mean %.2e" % (worst_l, worst_s))
+    assert torch.equal(state, whole["state"])            # the recurrent state does not depend on the chunking
     part = m.forward(mel[PICK].contiguous(), m.zero_state(len(PICK)))
     assert torch.equal(part["logits"], whole["logits"][PICK]) and torch.equal(part["state"], whole["state"][:, PICK])
-    # the recurrent state is chunking-independent bitwise; the projection's activation range is per call (reference)
-    state, pos = m.zero_state(b), 0
-    for n in (150, 22, 128):
-        _, state = m.step(mel[:, pos:pos + n].contiguous(), state)
-        pos += n
-    assert torch.equal(state, whole["state"])
 
 
 def test_stress_config_full_size_against_the_c_oracle(oracle_c):

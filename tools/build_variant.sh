@@ -12,7 +12,7 @@ W=$(mktemp -d)
 mkdir -p $W/keyword_spotting_amd && cp -r $ROOT/keyword_spotting_amd/csrc $W/keyword_spotting_amd/csrc && rm -rf $W/keyword_spotting_amd/csrc/_obj
 FLAGS=()
 while [ $# -gt 0 ]; do
-  if [ "$1" == "--patch" ]; then (cd $W && patch -p1 < $(realpath $2)); shift 2; else FLAGS+=("$1"); shift; fi
+  if [ "$1" == "--patch" ]; then P=$(realpath $2); (cd $W && patch -s -p1 < $P); shift 2; else FLAGS+=("$1"); shift; fi
 done
 C=$W/keyword_spotting_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$ROOT/include -I$C -Wno-unused-value -Wno-unused-result "${FLAGS[@]}" \
