@@ -13,6 +13,7 @@
  *   kws_ctc_decode             utils/prediction.py:18 ctc_decode, :65 ctc_decode2, :89 ctc_decode_strict
  *   kws_ctc_predict            utils/prediction.py:111 ctc_predict
  *   kws_vad                    utils/basic_vad.py:17 vad
+ *   kws_stream_feed            one iteration of HotwordDetector.start's loop, detector.py:158-209, for B streams
  *   kws_octbit_matmul          REGISTER_OP("OctbitMatMul") octbit/octbit_ops_reg.cc:7-15,
  *                              OctbitMatMulOp::Compute octbit/octbit_mat_mul_op.cc:49-183
  *   kws_octbit_quantize        octize_weight_int8_signed octbit/octbit_graph.py:191-215
@@ -190,6 +191,27 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres,
 int kws_window_destroy(kws_window_handle h);
 int kws_window_step(kws_window_handle h, const float* softmax /*[B,T,C]*/, int T, const uint8_t* clear_before,
                     const char* label, int32_t* hit /*[B]*/, uint8_t* restart /*[B] or NULL*/, void* stream);
+
+/* The whole loop iteration of detector.py:158-209 for B streams as ONE call (device-side stream manager, native):
+ *   data = ring_buffer.get()                      `pcm` [B,n]: float samples, or int16 PCM scaled by 2^-15 (:40-43,74-79)
+ *   vad(data, vad_thres) false -> clean_state() + prob_queue.clear()                                   (:168-177)
+ *   data = concatenate(res, data); res = data[-keep:]      carried samples, never materialised          (:179-183)
+ *   softmax, state = sess.run(...)                 front-end + GRU stack on the carried state           (:190-196)
+ *   prob_queue.add(softmax); ctc_decode2 over the window; ctc_predict(label)                            (:195-201)
+ *   on a hit: window cleared, state reset requested for the next chunk                                  (:202-208)
+ * i.e. kws_vad -> kws_frontend_run_carry -> kws_step -> kws_window_step with the mask logic between them fused into
+ * the first kernel and no host work per stream.  The handle BORROWS the model, front-end and window handles (they must
+ * outlive it) and the caller-owned device buffers `state` [L,B,H] (zero it to start) and `restart` [B] u8 (zero it);
+ * it owns the sample carry, the mel / softmax staging and the masks.  Fewer than fft_size samples in total so far:
+ * everything is carried, hit = 0 (as the front-end yields no frame).  `label`: digits '1'..'9'. */
+typedef struct kws_stream* kws_stream_handle;
+int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window_handle window, int B, int max_chunk_samples,
+                      float vad_thres, const char* label, float* state, uint8_t* restart, kws_stream_handle* out);
+int kws_stream_destroy(kws_stream_handle h);
+/* Forgets the carried samples (the model state, restart mask and window belong to the caller). */
+int kws_stream_reset(kws_stream_handle h);
+int kws_stream_feed(kws_stream_handle h, const void* pcm /*[B,n] device*/, int n, int pcm_int16, int32_t* hit /*[B] device*/,
+                    void* stream);
 
 /* OctbitMatMul: out[A,N] = (sum_k u8(x)[a,k] * Wq[n,k] - signed*bias[n]) * scale_w * s_x.
  *   x [A,K] f32, Wq [N,K] s8 (pre-transposed), bias [N] f32, out [A,N] f32.  K % 64 == 0, scale_w > 0.

@@ -114,6 +114,51 @@ __global__ void __launch_bounds__(256) vad_kernel(const float* __restrict__ pcm,
     }
 }
 
+// The head of one loop iteration of detector.py:158-177 for every stream, in one pass over the new chunk: the samples
+// as the ring buffer hands them over (int16 -> float by 2^-15, detector.py:40-43,74-79; float PCM is read as it is),
+// vad(data, thres) (utils/basic_vad.py:17-18; same summation order as vad_kernel, so the decisions are identical), and
+// the masks the rest of the iteration consumes: silent (-> clear the decode window before the chunk is added) and
+// reset = silent | restart (-> the GRU starts this chunk from the zero state: clean_state()).
+template <typename SampleT>
+__global__ void __launch_bounds__(256) vad_gate_kernel(const SampleT* __restrict__ pcm, int N, float thres, float* __restrict__ pcm_f32,
+                                                       const uint8_t* __restrict__ restart, uint8_t* __restrict__ silent,
+                                                       uint8_t* __restrict__ reset) {
+    const int b = blockIdx.x;
+    const SampleT* x = pcm + (size_t)b * N;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        float v;
+        if constexpr (sizeof(SampleT) == 2) {
+            v = (float)x[i] * (1.0f / 32768.0f);
+            pcm_f32[(size_t)b * N + i] = v;
+        } else {
+            v = x[i];
+        }
+        acc += fabsf(v);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = (part[0] + part[1]) + (part[2] + part[3]);
+        const uint8_t quiet = total > thres ? 0 : 1;
+        silent[b] = quiet;
+        reset[b] = (quiet || (restart && restart[b])) ? 1 : 0;
+    }
+}
+
+hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,
+                           uint8_t* silent, uint8_t* reset, hipStream_t st) {
+    if (pcm_int16)
+        hipLaunchKernelGGL(vad_gate_kernel<int16_t>, dim3(B), dim3(256), 0, st, static_cast<const int16_t*>(pcm), N, thres, pcm_f32,
+                           restart, silent, reset);
+    else
+        hipLaunchKernelGGL(vad_gate_kernel<float>, dim3(B), dim3(256), 0, st, static_cast<const float*>(pcm), N, thres, pcm_f32,
+                           restart, silent, reset);
+    return hipGetLastError();
+}
+
 hipError_t launch_ctc_decode(int kind, const float* softmax, const int32_t* lengths, int B, int T, int C,
                              int lockout, float thres, float loose_thres, int32_t* words, int32_t* counts,
                              int max_words, hipStream_t st) {

@@ -100,6 +100,23 @@ struct kws_window {
     int *lens = nullptr, *head = nullptr, *count = nullptr;
 };
 
+struct kws_stream {
+    kws_model* model = nullptr;
+    kws_frontend* fe = nullptr;
+    kws_window* win = nullptr;
+    int B = 0, max_chunk = 0, tmax = 0, n_carry = 0, cur = 0;
+    float vad_thres = 0.f;
+    char label[17] = {0};
+    float* state = nullptr;          // caller-owned [L,B,H]
+    uint8_t* restart = nullptr;      // caller-owned [B]
+    float* carry[2] = {nullptr, nullptr};   // [B, fft - 1] each: the carried samples ping-pong
+    float* pcm_f32 = nullptr;        // [B, max_chunk]  int16 input widened here
+    float* mel = nullptr;            // [B, tmax, n_mel]
+    float* softmax = nullptr;        // [B, tmax, C]
+    uint8_t* silent = nullptr;       // [B]
+    uint8_t* reset = nullptr;        // [B]
+};
+
 struct kws_frontend {
     kws_frontend_config cfg;
     float* d_tables = nullptr;
@@ -1095,6 +1112,101 @@ int kws_frontend_run_carry(kws_frontend_handle h, const float* carry, int n_carr
                                               static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return hip_fail(e, "launch carry_tail");
     }
+    return KWS_OK;
+}
+
+int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window_handle window, int B, int max_chunk_samples,
+                      float vad_thres, const char* label, float* state, uint8_t* restart, kws_stream_handle* out) {
+    if (!out) return fail(KWS_ERR_INVALID_ARGUMENT, "out handle pointer is null");
+    *out = nullptr;
+    if (!model || !frontend || !window || !state || !restart || !label) return fail(KWS_ERR_INVALID_ARGUMENT, "null argument");
+    if (B < 1 || max_chunk_samples < 1) return fail(KWS_ERR_INVALID_ARGUMENT, "bad stream shape B=%d max_chunk_samples=%d", B, max_chunk_samples);
+    const int n = (int)strlen(label);
+    if (n > 16) return fail(KWS_ERR_INVALID_ARGUMENT, "label longer than 16 digits");
+    for (int i = 0; i < n; ++i)
+        if (label[i] < '1' || label[i] > '9') return fail(KWS_ERR_INVALID_ARGUMENT, "label must be digits 1..9, got '%s'", label);
+    if (frontend->cfg.n_mel != model->cfg.n_mel)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "front-end produces %d mel bins, the model takes %d", frontend->cfg.n_mel, model->cfg.n_mel);
+    if (window->B != B || window->C != model->cfg.num_classes)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "window was created for B=%d C=%d, stream needs B=%d C=%d", window->B, window->C, B,
+                    model->cfg.num_classes);
+    const int fft = frontend->cfg.fft_size;
+    const int tmax = kws_frontend_frames(&frontend->cfg, max_chunk_samples + fft - 1);
+    if (tmax > window->tmax)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "chunks of %d samples give up to %d frames, the window holds %d per chunk", max_chunk_samples,
+                    tmax, window->tmax);
+    kws_stream* s = new (std::nothrow) kws_stream();
+    if (!s) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->model = model; s->fe = frontend; s->win = window; s->B = B; s->max_chunk = max_chunk_samples; s->tmax = tmax;
+    s->vad_thres = vad_thres; s->state = state; s->restart = restart;
+    memcpy(s->label, label, n);
+    const size_t carry_bytes = (size_t)B * (fft - 1) * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->carry[0]), carry_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->carry[1]), carry_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->pcm_f32), (size_t)B * max_chunk_samples * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->mel), (size_t)B * (tmax > 0 ? tmax : 1) * model->cfg.n_mel * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->softmax), (size_t)B * (tmax > 0 ? tmax : 1) * model->cfg.num_classes * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->silent), (size_t)B);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->reset), (size_t)B);
+    if (e != hipSuccess) { kws_stream_destroy(s); return hip_fail(e, "hipMalloc(stream buffers)"); }
+    const int rc = kws_reserve(model, B, tmax);            // the GRU step of a chunk never allocates afterwards
+    if (rc != KWS_OK) { kws_stream_destroy(s); return rc; }
+    *out = s;
+    return KWS_OK;
+}
+
+int kws_stream_destroy(kws_stream_handle h) {
+    if (!h) return KWS_OK;
+    hipDeviceSynchronize();
+    for (float* p : {h->carry[0], h->carry[1], h->pcm_f32, h->mel, h->softmax}) if (p) hipFree(p);
+    if (h->silent) hipFree(h->silent);
+    if (h->reset) hipFree(h->reset);
+    delete h;
+    return KWS_OK;
+}
+
+int kws_stream_reset(kws_stream_handle h) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    h->n_carry = 0;
+    return KWS_OK;
+}
+
+int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, int32_t* hit, void* stream) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (n < 0 || n > h->max_chunk) return fail(KWS_ERR_INVALID_ARGUMENT, "chunk of %d samples outside [0,%d]", n, h->max_chunk);
+    if (!hit || (!pcm && n > 0)) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const kws_frontend_config& fc = h->fe->cfg;
+    const int fft = fc.fft_size, hop = fc.hop_size, B = h->B;
+    const int total = h->n_carry + n;
+    const float* chunk = pcm_int16 ? h->pcm_f32 : static_cast<const float*>(pcm);
+    const float* carry = h->carry[h->cur];
+    float* next = h->carry[h->cur ^ 1];
+    if (total < fft) {
+        // not a full frame yet: everything is carried, no model run, no decision (the int16 samples still have to be widened)
+        if (pcm_int16 && n > 0) {
+            hipError_t e = kws::launch_vad_gate(pcm, 1, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset, st);
+            if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
+        }
+        if (total > 0) {
+            hipError_t e = kws::launch_carry_tail(h->n_carry ? carry : chunk, h->n_carry, n ? chunk : carry, n, next, total, B, st);
+            if (e != hipSuccess) return hip_fail(e, "launch carry_tail");
+        }
+        KWS_HIP(hipMemsetAsync(hit, 0, (size_t)B * sizeof(int32_t), st));
+        h->n_carry = total; h->cur ^= 1;
+        return KWS_OK;
+    }
+    hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset, st);
+    if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
+    const int keep = (total - fft) % hop + (fft - hop);                                  // detector.py:181-182
+    int rc = kws_frontend_run_carry(h->fe, h->n_carry ? carry : nullptr, h->n_carry, chunk, n, B, h->mel, next, keep, st);
+    if (rc != KWS_OK) return rc;
+    const int T = kws_frontend_frames(&fc, total);
+    rc = kws_step(h->model, h->mel, h->state, nullptr, h->softmax, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, T, st);
+    if (rc != KWS_OK) return rc;
+    rc = kws_window_step(h->win, h->softmax, T, h->silent, h->label, hit, h->restart, st);
+    if (rc != KWS_OK) return rc;
+    h->n_carry = keep; h->cur ^= 1;
     return KWS_OK;
 }
 

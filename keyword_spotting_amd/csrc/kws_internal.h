@@ -175,6 +175,9 @@ hipError_t launch_ctc_predict(const int32_t* words, const int32_t* counts, int B
 hipError_t launch_vad(const float* pcm, int B, int N, float thres, uint8_t* speech, float* abs_sum,
                       hipStream_t st);
 
+hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,
+                           uint8_t* silent, uint8_t* reset, hipStream_t st);
+
 // octbit_kernels.hip
 hipError_t launch_octbit_matmul(const float* x, const int8_t* Wq, float scale_w, const float* bias,
                                 float* out, int A, int K, int N, int per_row, float* range_ws,

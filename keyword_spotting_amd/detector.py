@@ -159,10 +159,11 @@ class HotwordDetector(object):
 
 
 class StreamManager(object):
-    """The same loop with every per-stream decision on the device: kws_vad -> reset mask ->
-    kws_step -> kws_window_step (15-chunk softmax ring, windowed ctc_decode2 + ctc_predict, trigger -> clear +
-    restart).  No per-stream Python; B in the thousands costs four launches per chunk.  Results are identical to
-    HotwordDetector (tests/test_gpu_detector.py)."""
+    """The same loop with every per-stream decision on the device.  feed_pcm is ONE native call
+    per chunk (kws_stream_feed: VAD gate -> front-end with sample carry -> GRU stack -> 15-chunk window with windowed
+    ctc_decode2 + ctc_predict, trigger -> clear + restart); feed takes mel chunks and chains kws_step and
+    kws_window_step itself.  No per-stream host work; results are identical to HotwordDetector
+    (tests/test_gpu_detector.py, tests/test_gpu_frontend.py)."""
 
     def __init__(self, model, batch, window_chunks=15, max_frames=32, vad_thres=30, label=None, decode_thres=0.4):
         import ctypes
@@ -178,10 +179,16 @@ class StreamManager(object):
         self.state = model.zero_state(self.batch)
         self.restart = torch.zeros(self.batch, dtype=torch.uint8, device=dev)     # reset requested by a trigger
         self.hit = torch.zeros(self.batch, dtype=torch.int32, device=dev)
-        self.softmax = None
-        self.res = None
+        self.max_frames = int(max_frames)
+        self._stream, self._stream_frontend = None, None
+
+    def _close_stream(self):
+        if getattr(self, "_stream", None) is not None and self._stream.value:
+            self._lib.kws_stream_destroy(self._stream)
+        self._stream, self._stream_frontend = None, None
 
     def close(self):
+        self._close_stream()
         if getattr(self, "_win", None) is not None and self._win.value:
             self._lib.kws_window_destroy(self._win)
             self._win.value = None
@@ -215,19 +222,34 @@ class StreamManager(object):
         return self.hit
 
     def feed_pcm(self, pcm_chunk, frontend):
-        """pcm_chunk [B, n]: float samples, or int16 PCM as the sound card delivers it (converted on the device
-        by buf_to_float, detector.py:74-79)."""
+        """pcm_chunk [B, n]: float samples, or int16 PCM as the sound card delivers it (widened on the device as
+        buf_to_float does, detector.py:74-79).  One native call per chunk (kws_stream_feed): VAD + reset masks, the
+        front-end on [carried samples | chunk] (detector.py:179-183, never concatenated), the GRU stack on the carried
+        state, the window / decode / trigger step.  -> hit [B] int32 device tensor."""
+        import ctypes
         chunk = torch.as_tensor(pcm_chunk)
         if chunk.dim() == 1:
             chunk = chunk.unsqueeze(0)
-        chunk = buf_to_float(chunk.to(self.model.device))
-        fft, hop = self.config.fft_size, self.config.hop_size
-        n = int(chunk.shape[1]) + (0 if self.res is None else int(self.res.shape[1]))
-        # detector.py:179-183 without materialising np.concatenate((self.res, data)): the front-end reads the
-        # carried samples and the chunk in place and hands back the next carry
-        keep = n if n < fft else (n - fft) % hop + (fft - hop)
-        mel, self.res = frontend.forward_carry(self.res, chunk, keep)
-        if n < fft:
-            self.hit.zero_()
-            return self.hit
-        return self.feed(mel, pcm_chunk=chunk)
+        if chunk.shape[0] != self.batch:
+            raise _lib.InvalidArgumentError(-1, "expected %d streams, got %d" % (self.batch, chunk.shape[0]))
+        if chunk.dtype == torch.int16:
+            is_i16 = 1
+        elif chunk.dtype.is_floating_point:
+            is_i16, chunk = 0, chunk.to(torch.float32)
+        else:
+            raise _lib.InvalidArgumentError(-1, "expected float or int16 PCM, got %s" % chunk.dtype)
+        chunk = chunk.to(self.model.device).contiguous()
+        dev = self.model.device
+        if self._stream is None or self._stream_frontend is not frontend:
+            self._close_stream()
+            self._stream = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                _lib.check(self._lib.kws_stream_create(self.model._handle, frontend._handle, self._win, self.batch,
+                                                       self.max_frames * int(self.config.hop_size), float(self.vad_thres),
+                                                       self.label, _lib.ptr(self.state), _lib.ptr(self.restart),
+                                                       ctypes.byref(self._stream)))
+            self._stream_frontend = frontend
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.kws_stream_feed(self._stream, _lib.ptr(chunk), int(chunk.shape[1]), is_i16, _lib.ptr(self.hit),
+                                                 _lib.current_stream_ptr()))
+        return self.hit

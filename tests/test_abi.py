@@ -109,3 +109,14 @@ def test_window_shape_limits_are_rejected_before_any_device_work():
     assert lib.kws_window_create(4, 0, 32, 6, 0.4, ctypes.byref(h)) == _lib.KWS_ERR_INVALID_ARGUMENT
     if not have_gpu():
         assert lib.kws_window_create(4, 64, 32, 6, 0.4, ctypes.byref(h)) == _lib.KWS_ERR_NO_DEVICE
+
+
+def test_stream_manager_entry_points_validate_arguments():
+    from keyword_spotting_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.kws_stream_create(None, None, None, 4, 3600, 30.0, b"1233", None, None, ctypes.byref(h)) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_stream_create(None, None, None, 4, 3600, 30.0, b"1233", None, None, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_stream_feed(None, None, 0, 0, None, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_stream_reset(None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_stream_destroy(None) == _lib.KWS_OK

@@ -32,7 +32,8 @@ for c in range(a.chunks):
 e1 = ev(); torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 # stage split
-data = torch.cat([mgr.res, pcm[:, :3600]], 1).contiguous()
+res = torch.zeros(a.batch, 320, device="cuda")
+data = torch.cat([res, pcm[:, :3600]], 1).contiguous()
 torch.cuda.synchronize(); s0 = ev()
 for _ in range(20): mel = fe.forward(data)
 s1 = ev()
@@ -48,7 +49,7 @@ silent = torch.zeros(a.batch, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize(); v0 = ev()
 for _ in range(20): sp = vad(chunk, 30)
 v1 = ev()
-for _ in range(20): d2 = torch.cat([mgr.res, chunk], 1); r2 = d2[:, -320:].contiguous()
+for _ in range(20): d2 = torch.cat([res, chunk], 1); r2 = d2[:, -320:].contiguous()
 v2 = ev()
 for _ in range(20):
     _lib.check(mgr._lib.kws_window_step(mgr._win, _lib.ptr(sm), 22, _lib.ptr(silent), mgr.label, _lib.ptr(mgr.hit), _lib.ptr(mgr.restart), _lib.current_stream_ptr()))
