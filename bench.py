@@ -167,13 +167,17 @@ def cpu_baseline(cfg, w, seconds_budget=25.0):
 
 
 def pmc_traffic_all():
-    """{kernel name: HBM bytes per launch} for every kernel of the latest committed PMC pass, and its path."""
+    """{kernel name: HBM bytes per launch} for every kernel of the latest committed PMC pass of THIS command
+    (profiles/r<round>_pmc.json, written by tools/prof.sh <tag> on bench.py's default workload; FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE), and its path.  The other r<round>_<variant>_pmc.json files belong to other workloads."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    import re
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")) if re.match(r"^r\d+_pmc\.json$", os.path.basename(f))]
     if not files:
         return {}, None
-    data = json.load(open(files[-1]))
-    return {k: c["hbm_bytes_per_launch"] for k, c in data.items() if "hbm_bytes_per_launch" in c}, os.path.relpath(files[-1], ROOT)
+    latest = max(files, key=lambda f: int(re.match(r"^r(\d+)_", os.path.basename(f)).group(1)))
+    data = json.load(open(latest))
+    return {k: c["hbm_bytes_per_launch"] for k, c in data.items() if "hbm_bytes_per_launch" in c}, os.path.relpath(latest, ROOT)
 
 
 def main(argv=None, model_factory=None):

@@ -97,18 +97,47 @@ __global__ void ctc_predict_kernel(const int32_t* __restrict__ words, const int3
 }
 
 // one workgroup per stream: sum |x| in fp32 (wave shuffle + LDS), compare with the threshold
-__global__ void __launch_bounds__(256) vad_kernel(const float* __restrict__ pcm, int N, float thres,
-                                                  uint8_t* __restrict__ speech, float* __restrict__ abs_sum) {
-    const int b = blockIdx.x;
-    const float* x = pcm + (size_t)b * N;
+// sum_n |x[n]| of one row by a 256-thread block (utils/basic_vad.py:17-18).  ONE summation order for every caller --
+// kws_vad and the stream manager's gate kernel must take identical decisions: 16-byte loads (4 samples per lane and
+// trip, 8 for int16) when the row allows it, per-thread partial sums, wave shuffles, then the four wave totals.
+template <typename SampleT>
+__device__ __forceinline__ float block_abs_sum(const SampleT* __restrict__ x, int N, float* __restrict__ widened) {
+    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;      // detector.py:40-43: int16 -> [-1, 1)
     float acc = 0.f;
-    for (int i = threadIdx.x; i < N; i += 256) acc += fabsf(x[i]);
+    const bool vec = (N & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(SampleT) - 1)) == 0 &&
+                     (!widened || (reinterpret_cast<uintptr_t>(widened) & 15) == 0);
+    if (vec) {
+        for (int i = threadIdx.x; i < N / 4; i += 256) {
+            float v[4];
+            if constexpr (sizeof(SampleT) == 2) {
+                const short4 q = reinterpret_cast<const short4*>(x)[i];
+                v[0] = (float)q.x * kScale; v[1] = (float)q.y * kScale; v[2] = (float)q.z * kScale; v[3] = (float)q.w * kScale;
+            } else {
+                const float4 q = reinterpret_cast<const float4*>(x)[i];
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            }
+            if (widened) reinterpret_cast<float4*>(widened)[i] = make_float4(v[0], v[1], v[2], v[3]);
+            acc += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
+        }
+    } else {
+        for (int i = threadIdx.x; i < N; i += 256) {
+            const float v = (float)x[i] * kScale;
+            if (widened) widened[i] = v;
+            acc += fabsf(v);
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
+    return (part[0] + part[1]) + (part[2] + part[3]);         // valid in thread 0
+}
+
+__global__ void __launch_bounds__(256) vad_kernel(const float* __restrict__ pcm, int N, float thres,
+                                                  uint8_t* __restrict__ speech, float* __restrict__ abs_sum) {
+    const int b = blockIdx.x;
+    const float total = block_abs_sum<float>(pcm + (size_t)b * N, N, nullptr);
     if (threadIdx.x == 0) {
-        const float total = (part[0] + part[1]) + (part[2] + part[3]);
         speech[b] = total > thres ? 1 : 0;
         if (abs_sum) abs_sum[b] = total;
     }
@@ -116,7 +145,7 @@ __global__ void __launch_bounds__(256) vad_kernel(const float* __restrict__ pcm,
 
 // The head of one loop iteration of detector.py:158-177 for every stream, in one pass over the new chunk: the samples
 // as the ring buffer hands them over (int16 -> float by 2^-15, detector.py:40-43,74-79; float PCM is read as it is),
-// vad(data, thres) (utils/basic_vad.py:17-18; same summation order as vad_kernel, so the decisions are identical), and
+// vad(data, thres) (utils/basic_vad.py:17-18; block_abs_sum, the summation kws_vad uses: identical decisions), and
 // the masks the rest of the iteration consumes: silent (-> clear the decode window before the chunk is added) and
 // reset = silent | restart (-> the GRU starts this chunk from the zero state: clean_state()).
 template <typename SampleT>
@@ -124,24 +153,8 @@ __global__ void __launch_bounds__(256) vad_gate_kernel(const SampleT* __restrict
                                                        const uint8_t* __restrict__ restart, uint8_t* __restrict__ silent,
                                                        uint8_t* __restrict__ reset) {
     const int b = blockIdx.x;
-    const SampleT* x = pcm + (size_t)b * N;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        float v;
-        if constexpr (sizeof(SampleT) == 2) {
-            v = (float)x[i] * (1.0f / 32768.0f);
-            pcm_f32[(size_t)b * N + i] = v;
-        } else {
-            v = x[i];
-        }
-        acc += fabsf(v);
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
+    const float total = block_abs_sum<SampleT>(pcm + (size_t)b * N, N, sizeof(SampleT) == 2 ? pcm_f32 + (size_t)b * N : nullptr);
     if (threadIdx.x == 0) {
-        const float total = (part[0] + part[1]) + (part[2] + part[3]);
         const uint8_t quiet = total > thres ? 0 : 1;
         silent[b] = quiet;
         reset[b] = (quiet || (restart && restart[b])) ? 1 : 0;
