@@ -15,7 +15,14 @@ while [ $# -gt 0 ]; do
   if [ "$1" == "--patch" ]; then P=$(realpath $2); (cd $W && patch -s -p1 < $P); shift 2; else FLAGS+=("$1"); shift; fi
 done
 C=$W/keyword_spotting_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$ROOT/include -I$C -Wno-unused-value -Wno-unused-result "${FLAGS[@]}" \
-  $C/*.hip -o $OUT/libkws_$NAME.so
+# per-file flags as in csrc/Makefile (FLAGS_<file>)
+OBJ=$W/obj; mkdir -p $OBJ
+for f in $C/*.hip; do
+  n=$(basename $f .hip); X=""
+  [ "$n" == "gru_bf16" ] && X="-mllvm -amdgpu-mfma-vgpr-form=1"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$C -Wno-unused-value -Wno-unused-result $X "${FLAGS[@]}" -c $f -o $OBJ/$n.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/*.o -o $OUT/libkws_$NAME.so
 rm -rf $W
 echo built $OUT/libkws_$NAME.so
