@@ -435,8 +435,16 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
     f32x4* biasl = xstage + NT * 64;                                                      // [3][NT][4 g] bias fragments
     const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * NT * 4));  // LAST only
 
-    const f32x4* wx = reinterpret_cast<const f32x4*>(p.wx);   // [NT][3][KCX4][64]
-    const f32x4* wh = reinterpret_cast<const f32x4*>(p.wh);   // [NT][3][NT][64]
+    // The weight stream (and the seam of a layer-by-layer launch) goes through BUFFER loads: lane offset in one VGPR that
+    // never changes, everything else in the scalar offset.  With flat global loads every fragment fetched per frame cost
+    // two or three VALU instructions of 64-bit address arithmetic -- about one per MFMA, beside an f32 MFMA stream that
+    // shares the FP32 pipe with them (profiles/r2_configC_pmc.json: 2.0 VALU instructions per MFMA).
+    const __amdgpu_buffer_rsrc_t wx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wx), (short)0, 0x7fffffff, 0x00020000);   // [NT][3][KCX4][64] float4
+    const __amdgpu_buffer_rsrc_t wh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wh), (short)0, 0x7fffffff, 0x00020000);   // [NT][3][NT][64] float4
+    const int lane16 = lane * 16;
+    auto bload = [&](const __amdgpu_buffer_rsrc_t& r, int frag) -> f32x4 {      // frag: wave-uniform fragment index (1 KiB each)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, frag * 1024, 0));
+    };
 
     // biases live in LDS (the accumulators are re-initialised from there every frame): at TPW = 4 the 48 registers
     // they would pin are the difference between fitting the 512-register file and spilling
@@ -463,6 +471,9 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
     const float* xrow = FIRST ? p.x_mel + (size_t)b * (p.t_stride ? p.t_stride : T) * I : nullptr;
     const f32x4* xprev = FIRST ? nullptr
                                : reinterpret_cast<const f32x4*>(p.x_prev) + (size_t)group * T * NT * 64 + lane;
+    const __amdgpu_buffer_rsrc_t xp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        FIRST ? const_cast<float*>(p.wh) : const_cast<float*>(reinterpret_cast<const float*>(p.x_prev + (size_t)group * T * NT * 64)),
+        (short)0, 0x7fffffff, 0x00020000);       // this group's [T][NT][64] float4 block of the seam
     const bool vec_ok = (I & 3) == 0;
     __syncthreads();
 
@@ -484,7 +495,7 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
         } else if (PIPE) {
             xb = xstage[k4 * 64 + lane];          // staged at the top of the frame (below)
         } else {
-            xb = xprev[((size_t)t * NT + k4) * 64];
+            xb = bload(xp_rsrc, t * NT + k4);
         }
         return xb;
     };
@@ -500,7 +511,7 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
 #pragma unroll
         for (int j = 0; j < RT; ++j)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) r.a[j][c] = wx[(((TPW * w + part * RT + j) * 3 + c) * KCX4 + kk) * 64 + lane];
+            for (int c = 0; c < 3; ++c) r.a[j][c] = bload(wx_rsrc, ((TPW * w + part * RT + j) * 3 + c) * KCX4 + kk);
         r.xb = x_operand(t, kk);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -509,13 +520,13 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
 #pragma unroll
         for (int j = 0; j < RT; ++j)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) r.a[j][c] = wh[(((TPW * w + part * RT + j) * 3 + c) * NT + kk) * 64 + lane];
+            for (int c = 0; c < 2; ++c) r.a[j][c] = bload(wh_rsrc, ((TPW * w + part * RT + j) * 3 + c) * NT + kk);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto load_c = [&](RowC& r, int q) {
         const int qq = q < NT * NP ? q : NT * NP - 1, kk = qq / NP, part = qq - kk * NP;
 #pragma unroll
-        for (int j = 0; j < RT; ++j) r.a[j] = wh[(((TPW * w + part * RT + j) * 3 + 2) * NT + kk) * 64 + lane];
+        for (int j = 0; j < RT; ++j) r.a[j] = bload(wh_rsrc, ((TPW * w + part * RT + j) * 3 + 2) * NT + kk);
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int t = 0; t < T; ++t) {
