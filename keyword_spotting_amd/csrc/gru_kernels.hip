@@ -469,11 +469,12 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
         }
     }
     const float* xrow = FIRST ? p.x_mel + (size_t)b * (p.t_stride ? p.t_stride : T) * I : nullptr;
-    const f32x4* xprev = FIRST ? nullptr
-                               : reinterpret_cast<const f32x4*>(p.x_prev) + (size_t)group * T * NT * 64 + lane;
     const __amdgpu_buffer_rsrc_t xp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         FIRST ? const_cast<float*>(p.wh) : const_cast<float*>(reinterpret_cast<const float*>(p.x_prev + (size_t)group * T * NT * 64)),
         (short)0, 0x7fffffff, 0x00020000);       // this group's [T][NT][64] float4 block of the seam
+    const __amdgpu_buffer_rsrc_t ho_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        LAST ? const_cast<float*>(p.wh) : reinterpret_cast<float*>(p.h_out + (size_t)group * T * NT * 64), (short)0, 0x7fffffff, 0x00020000);
+    constexpr int kSysScope = 1 | 16;            // cache-policy bits sc0 | sc1: system scope, past the non-coherent cache levels
     const bool vec_ok = (I & 3) == 0;
     __syncthreads();
 
@@ -552,13 +553,12 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
             // The frame's input block was written by a workgroup on another CU / XCD while this kernel runs:
             // system-scope (sc0 sc1) loads go past the non-coherent cache levels, dword by dword, at memory
             // latency -- so the whole block is fetched at once (all loads in flight) and parked in LDS.
+            // (16-byte sc0 sc1 buffer loads: dword-granular system-scope accesses cost ~6x the fabric time per byte;
+            // tearing is no concern, the rows are ordered by the frame counter)
             f32x4 xv[NT / 4];
 #pragma unroll
-            for (int i = 0; i < NT / 4; ++i) {
-                const float* src = reinterpret_cast<const float*>(xprev + ((size_t)t * NT + (w + 4 * i)) * 64);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xv[i][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            for (int i = 0; i < NT / 4; ++i)
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xp_rsrc, lane16, (t * NT + (w + 4 * i)) * 1024, kSysScope));
 #pragma unroll
             for (int i = 0; i < NT / 4; ++i) xstage[(w + 4 * i) * 64 + lane] = xv[i];
             __syncthreads();
@@ -661,9 +661,8 @@ __device__ __forceinline__ void gru_layer_generic_body(const GruLayerParams& p, 
                 const f32x4 o = hreg[j];
                 float4* dst = p.h_out + ((size_t)group * T + t) * NT * 64 + n * 64 + lane;
                 if (PIPE) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        __hip_atomic_store(reinterpret_cast<float*>(dst) + e, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), ho_rsrc, lane16, (t * NT + n) * 1024, kSysScope);
                 } else {
                     *dst = make_float4(o[0], o[1], o[2], o[3]);
                 }
