@@ -95,7 +95,7 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
 int kws_destroy(kws_handle h);
 
 /* Kernel family used by kws_step (fp32): AUTO picks the register-resident kernels when the shape allows
- * (hidden == 128 and n_mel in {40, 60}), else the generic ones (hidden 64/128/256, any n_mel).
+ * (hidden == 128 and n_mel in {32, 40, 48, 60, 64}), else the generic ones (hidden 64/128/256, any n_mel).
  * RESIDENT on an unsupported shape -> KWS_ERR_UNSUPPORTED.  Ignored by the bf16 stack. */
 int kws_set_kernel(kws_handle h, int kind);
 /* Pre-sizes the handle's scratch for calls of up to B streams x T frames: afterwards kws_step on any shape whose

@@ -753,7 +753,10 @@ int gru_resident_kcx(int in_dim, bool first) { return first ? (in_dim + 3) / 4 :
 bool gru_resident_supported(int hidden, int in_dim, bool first) {
     if (hidden != 128) return false;
     if (!first) return in_dim == 128;
-    return in_dim == 40 || in_dim == 60;     // instantiated KCX = 10, 15; rows must be whole float4s
+    // instantiated KCX = 8, 10, 12, 15, 16 (rows must be whole float4s, and the cooperative mel staging needs
+    // 4 streams x KCX float4 pieces <= 64 lanes): the reference's 40 (README.md:17) and 60 (config/rnn_config.py:63),
+    // plus the other common front-end widths up to 64
+    return in_dim == 32 || in_dim == 40 || in_dim == 48 || in_dim == 60 || in_dim == 64;
 }
 
 template <typename K>
@@ -772,8 +775,11 @@ hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool l
     const size_t lds = resident_lds_bytes(p.KCX, first, last);
 #define KWS_RES(KCX_, F_, L_) return launch_with_lds(gru_layer_resident<KCX_, F_, L_>, p, lds, st)
     if (first) {
+        if (p.KCX == 8) { if (last) KWS_RES(8, true, true); else KWS_RES(8, true, false); }
         if (p.KCX == 10) { if (last) KWS_RES(10, true, true); else KWS_RES(10, true, false); }
+        if (p.KCX == 12) { if (last) KWS_RES(12, true, true); else KWS_RES(12, true, false); }
         if (p.KCX == 15) { if (last) KWS_RES(15, true, true); else KWS_RES(15, true, false); }
+        if (p.KCX == 16) { if (last) KWS_RES(16, true, true); else KWS_RES(16, true, false); }
         return hipErrorInvalidValue;
     }
     if (last) KWS_RES(32, false, true); else KWS_RES(32, false, false);

@@ -468,7 +468,7 @@ int kws_set_kernel(kws_handle h, int kind) {
     if (kind == KWS_KERNEL_RESIDENT)
         for (const auto& L : h->layers)
             if (!L.resident_ok)
-                return fail(KWS_ERR_UNSUPPORTED, "resident kernels need hidden=128 and n_mel in {40, 60}; got hidden=%d n_mel=%d",
+                return fail(KWS_ERR_UNSUPPORTED, "resident kernels need hidden=128 and n_mel in {32, 40, 48, 60, 64}; got hidden=%d n_mel=%d",
                             h->cfg.hidden, h->cfg.n_mel);
     h->kernel_kind = kind;
     return KWS_OK;

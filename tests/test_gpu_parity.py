@@ -25,13 +25,15 @@ def _cfg_tuple(shape, use_relu=0, clip=-1.0):
     return shape + (use_relu, clip)
 
 
-SHAPES = {"A": (40, 128, 2, 6), "B": (60, 128, 2, 6), "C": (60, 256, 4, 6)}
+SHAPES = {"A": (40, 128, 2, 6), "B": (60, 128, 2, 6), "C": (60, 256, 4, 6),
+          "D": (64, 128, 2, 6), "E": (32, 128, 1, 6), "F": (48, 128, 3, 6)}     # the other resident front-end widths
 
 
 @pytest.mark.parametrize("name,kernel,batch,frames", [
     ("A", "resident", 37, 50), ("A", "generic", 37, 50), ("A", "resident", 1, 300),
     ("A", "resident", 16, 1), ("A", "resident", 33, 7), ("B", "resident", 20, 23), ("B", "generic", 5, 22),
-    ("C", "generic", 20, 12), ("C", "auto", 3, 40)])
+    ("C", "generic", 20, 12), ("C", "auto", 3, 40),
+    ("D", "resident", 19, 30), ("E", "resident", 35, 26), ("F", "resident", 8, 41)])
 def test_logits_state_softmax_match_oracle(oracle_c, name, kernel, batch, frames):
     shape = SHAPES[name]
     i, h, l, c = shape
