@@ -763,6 +763,10 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     {
         const int rc = check_pipe_error(h);      // raised by an earlier layer-pipelined step of this handle
         if (rc != KWS_OK) return rc;
+        // the handle's weights and scratch live on the device that was current at kws_create
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess && dev != h->device)
+            return fail(KWS_ERR_INVALID_ARGUMENT, "handle was created on device %d, the current device is %d", h->device, dev);
     }
     if (h->ovl_tail_valid) {
         // the previous call ran its upper layers on the handle's own streams: whatever stream this call comes in on,

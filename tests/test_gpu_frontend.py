@@ -229,8 +229,10 @@ def test_int16_pcm_gives_the_same_decisions_in_both_detector_classes():
     pcm16[1, 3600 * 2:3600 * 4] = (pcm16[1, 3600 * 2:3600 * 4] // 4000)           # near-silent chunks: sum|x| < 30
     det = HotwordDetector(DeployModel(cfg, w), batch=4, label="12")
     mgr = StreamManager(DeployModel(cfg, w), 4, label="12")
-    for c in range(8):
-        piece = pcm16[:, 3600 * c:3600 * (c + 1)]
+    pos = 0
+    for n in (100, 250, 3600, 3601, 3599, 1, 3600, 3600, 3600, 3600):       # incl. less than one frame in total, odd lengths
+        piece = pcm16[:, pos:pos + n]
+        pos += n
         want = np.zeros(4, np.int32)
         want[det.feed_pcm(torch.from_numpy(piece), fe)] = 1
         got = mgr.feed_pcm(torch.from_numpy(piece), fe).cpu().numpy()

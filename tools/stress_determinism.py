@@ -31,8 +31,33 @@ def repeat(name, cfg, B, T, n, kernel="auto"):
           % (name, B, T, bad, n, len(kinds), sorted(kinds.values(), reverse=True)[:5], first_bad))
     return bad
 
+def repeat_stream(n):
+    """kws_stream_feed: the same chunk sequence replayed on fresh managers must give the same hits and state."""
+    from keyword_spotting_amd.detector import StreamManager
+    from keyword_spotting_amd.frontend import MelFrontend
+    import numpy as np
+    cfg = get_config()
+    w = weights.init_weights(cfg, seed=5)
+    w["Wfc"] = (w["Wfc"] * 3).astype(np.float32)
+    fe = MelFrontend(cfg)
+    B = 4096
+    pcm = (torch.randn(B, 3600 * 6, device="cuda") * 0.2 * 32768).clamp(-32768, 32767).to(torch.int16)
+    ref, bad = None, 0
+    for i in range(max(2, n // 10)):
+        mgr = StreamManager(DeployModel(cfg, w), B, label="12")
+        hits = [mgr.feed_pcm(pcm[:, 3600 * c:3600 * (c + 1)], fe).clone() for c in range(6)]
+        got = (torch.stack(hits), mgr.state.clone())
+        if ref is None:
+            ref = got
+        elif not (torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])):
+            bad += 1
+        mgr.close()
+    print("%-44s B=%d: %d / %d replays differ; %d hits" % ("kws_stream_feed, int16 PCM, 6 chunks", B, bad, max(2, n // 10) - 1, int(ref[0].sum())))
+    return bad
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 tot = 0
+tot += repeat_stream(n)
 tot += repeat("pipelined 4xGRU h=256 (configs[4])", get_config(n_mel=60, hidden_size=256, num_layers=4), 1024, 60, n)
 tot += repeat("pipelined 2xGRU h=128 generic", get_config(), 2048, 60, n, kernel="generic")
 tot += repeat("pipelined 8xGRU h=64", get_config(hidden_size=64, num_layers=8), 512, 60, n)
