@@ -233,6 +233,8 @@ def main(argv=None, model_factory=None):
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if args.dist_backend == "nccl" and world > torch.cuda.device_count():
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU over RCCL)" % (world, torch.cuda.device_count()))
         device = torch.device("cuda", local_rank % torch.cuda.device_count())
         torch.cuda.set_device(device)
         from keyword_spotting_amd.rnn_ctc import DeployModel
