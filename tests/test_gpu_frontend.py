@@ -238,3 +238,43 @@ def test_int16_pcm_gives_the_same_decisions_in_both_detector_classes():
         got = mgr.feed_pcm(torch.from_numpy(piece), fe).cpu().numpy()
         np.testing.assert_array_equal(got, want)
         assert torch.equal(mgr.state, det.state)
+
+
+@pytest.mark.parametrize("seed,as_int16", [(261, False), (262, True)])
+def test_native_loop_random_chunk_lengths_equal_the_host_mirror(seed, as_int16):
+    """kws_stream_feed against the HotwordDetector mirror of detector.py:158-209 over 50 chunks of random length
+    (1 .. 5000 samples: sub-frame chunks, odd lengths, chunks that yield 0 .. 31 frames), a label that fires, silent
+    stretches that trip the VAD reset -- hits and recurrent state identical after every chunk."""
+    from keyword_spotting_amd.detector import HotwordDetector, StreamManager
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg, fe = _frontend()
+    w = G.init_weights(seed=3)
+    w["Wfc"] = (w["Wfc"] * 3).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    b = 7
+    # a one-word label this random model really emits on noise (random weights never spell "1233")
+    probe = DeployModel(cfg, w)
+    sm = probe.forward(fe.forward(torch.from_numpy((rng.standard_normal((b, 8000)) * 0.2).astype(np.float32))),
+                       probe.zero_state(b), want_logits=False)["softmax"].cpu().numpy()
+    words = np.concatenate([D.ctc_decode2(sm[k], 6)[1::2] for k in range(b)])
+    assert words.size > 0
+    label = str(int(np.bincount(words).argmax()))
+    det = HotwordDetector(DeployModel(cfg, w), batch=b, label=label)
+    mgr = StreamManager(DeployModel(cfg, w), b, label=label)
+    fired = 0
+    for c in range(50):
+        n = int(rng.choice([rng.integers(1, 400), rng.integers(400, 5001), 3600]))
+        x = rng.standard_normal((b, n)) * 0.2
+        quiet = rng.random(b) < 0.15
+        x[quiet] *= 1e-4                                             # sum|x| far below the VAD threshold of 30
+        if as_int16:
+            piece = torch.from_numpy((x * 32768).clip(-32768, 32767).astype(np.int16))
+        else:
+            piece = torch.from_numpy(x.astype(np.float32))
+        want = np.zeros(b, np.int32)
+        want[det.feed_pcm(piece, fe)] = 1
+        got = mgr.feed_pcm(piece, fe).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg="chunk %d of %d samples" % (c, n))
+        assert torch.equal(mgr.state, det.state), (c, n)
+        fired += int(want.sum())
+    assert fired > 0
