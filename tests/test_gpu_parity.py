@@ -230,3 +230,26 @@ def test_full_size_properties(oracle_c):
         assert torch.equal(lg, whole["logits"][:, pos:pos + n])
         pos += n
     assert torch.equal(state, whole["state"])
+
+
+@pytest.mark.parametrize("kernel,precision", [("resident", "fp32"), ("generic", "fp32"), ("auto", "bf16")])
+def test_saturating_inputs_stay_finite_and_match_the_oracle(kernel, precision):
+    """Mel frames of magnitude 1e3..1e4 drive every gate deep into saturation: exp2 overflows to inf and the reciprocal
+    returns 0 -- sigmoid/tanh must land exactly on 0 / 1 / -1 like the oracle's, never on NaN."""
+    w = G.init_weights(seed=11)
+    b, t = 21, 40
+    mel = G.synthetic_mel(b, t, 40, seed=12) * np.float32(2e3)
+    mel[3] *= 0                                                       # an all-zero stream beside them
+    st0 = (0.9 * np.random.default_rng(13).standard_normal((2, b, 128))).clip(-1, 1).astype(np.float32)
+    m = _model(SHAPES["A"], w, kernel, precision=precision)
+    r = m.forward(torch.from_numpy(mel), torch.from_numpy(st0))
+    got_l, got_s = r["logits"].cpu().numpy(), r["state"].cpu().numpy()
+    assert np.isfinite(got_l).all() and np.isfinite(got_s).all() and np.isfinite(r["softmax"].cpu().numpy()).all()
+    if precision == "fp32":
+        want_l, want_s = G.gru_forward(w, mel, st0, dtype=np.float64)
+        tol_l, tol_s = 5e-4, 1e-4        # layer-0 pre-activations ~1e4: fp32 products carry ~1e-3 absolute, gates are saturated
+    else:
+        want_l, want_s = G.gru_forward_bf16(w, mel, st0)
+        tol_l, tol_s = 8e-2, 3e-2
+    assert np.abs(got_s - want_s).max() < tol_s and np.abs(got_l - want_l).max() < tol_l
+    np.testing.assert_allclose(r["softmax"].cpu().numpy().sum(-1), 1.0, atol=1e-5)
