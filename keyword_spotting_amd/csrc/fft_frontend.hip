@@ -1,0 +1,265 @@
+// PCM -> mel front-end of the deploy graph for the reference's frame length, as a real mixed-radix FFT.
+//   frames = tf_frame(x, 400, 160)            utils/stft.py:27-81  (no padding, NO window function)
+//   linearspec = |rfft(frames, 400)|          models/rnn_ctc.py:137
+//   melspec = linearspec @ mel_basis^T        models/rnn_ctc.py:139-149
+// (frontend_kernels.hip keeps the dense-DFT kernel for every other frame length.)
+//
+// 400 = 16 x 25, n = 16 n1 + n2, k = k1 + 25 k2 (Cooley-Tukey):
+//     X[k1 + 25 k2] = sum_{n2<16} W16^{n2 k2} * ( W400^{n2 k1} * Y_{n2}[k1] ),   Y_{n2}[k1] = sum_{n1<25} x[16 n1 + n2] W25^{n1 k1}
+// Stage 1: the 25-point DFT of a REAL decimated sequence, one per lane (lane = (frame j of 4, n2)), as 5 x 5 with
+//   n1 = 5a + b, k1 = c + 5d:  Z_b[c] = sum_a x[5a+b] W5^{ac} (real input: c = 0,1,2 suffice),
+//   Y[c + 5d] = sum_b W5^{bd} (W25^{bc} Z_b[c]).  Y is Hermitian, so only k1 = 0..12 is kept, and those thirteen come
+//   from c in {0,1,2} alone: Y3 = conj Y22, Y4 = conj Y21, Y8 = conj Y17, Y9 = conj Y16.
+// Stage 2: for k1 = 0..12 a 16-point complex FFT over n2 (radix 4 x 4) gives X[k1 + 25 k2], k2 = 0..15.  Those 208 values
+//   hold every bin 0..200 exactly once: k <= 200 directly, k > 200 as the mirror 400 - k (|X[400-k]| = |X[k]|; the bins of
+//   residue 13..24 mod 25), and k1 = 0, k2 >= 9 are duplicates that the mel table zeroes.
+// Between the stages the 13 x 16 complex values of a frame cross lanes through LDS (one transpose, wave-private: a
+// workgroup is ONE wave = 16 frames, no barrier anywhere).  In stage 2 lane = (g, frame f of 16) takes k1 = 4q + g in pass
+// q, so its sixteen magnitudes are -- as they stand in registers -- the B operands (k = g, n = f) of the mel projection on
+// v_mfma_f32_16x16x4_f32; the order of the bins along K is free, the basis fragments are packed to match (kws_api.hip).
+// ~9 kflop per frame on the VALU instead of the 100 kflop of the dense contraction.
+#include "gru_device.h"
+
+#pragma clang fp contract(off)      // only the fmaf() written below fuse: every frame sees one fixed instruction sequence
+
+namespace kws {
+
+namespace {
+
+struct c32 { float re, im; };
+__device__ __forceinline__ c32 operator+(c32 a, c32 b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ c32 operator-(c32 a, c32 b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ c32 cmul(c32 a, float c, float s) {           // a * (c + i s)
+    return {fmaf(-a.im, s, a.re * c), fmaf(a.re, s, a.im * c)};
+}
+__device__ __forceinline__ c32 conj(c32 a) { return {a.re, -a.im}; }
+
+constexpr float kC1 = 0.30901699437494742f, kC2 = -0.80901699437494742f;   // cos(2 pi/5), cos(4 pi/5)
+constexpr float kS1 = 0.95105651629515357f, kS2 = 0.58778525229247313f;    // sin(2 pi/5), sin(4 pi/5)
+
+// 5-point DFT of a real sequence: z0 (real), z1, z2 (z3 = conj z2, z4 = conj z1)
+__device__ __forceinline__ void rdft5(float x0, float x1, float x2, float x3, float x4, float& z0, c32& z1, c32& z2) {
+    const float sa = x1 + x4, da = x1 - x4, sb = x2 + x3, db = x2 - x3;
+    z0 = x0 + sa + sb;
+    z1.re = fmaf(kC2, sb, fmaf(kC1, sa, x0));
+    z2.re = fmaf(kC1, sb, fmaf(kC2, sa, x0));
+    z1.im = fmaf(-kS2, db, -kS1 * da);
+    z2.im = fmaf(kS1, db, -kS2 * da);
+}
+// 5-point DFT of a complex sequence
+__device__ __forceinline__ void cdft5(c32 t0, c32 t1, c32 t2, c32 t3, c32 t4, c32& y0, c32& y1, c32& y2, c32& y3, c32& y4) {
+    const c32 sa = t1 + t4, da = t1 - t4, sb = t2 + t3, db = t2 - t3;
+    y0 = t0 + sa + sb;
+    const c32 a1 = {fmaf(kC2, sb.re, fmaf(kC1, sa.re, t0.re)), fmaf(kC2, sb.im, fmaf(kC1, sa.im, t0.im))};
+    const c32 a2 = {fmaf(kC1, sb.re, fmaf(kC2, sa.re, t0.re)), fmaf(kC1, sb.im, fmaf(kC2, sa.im, t0.im))};
+    const c32 b1 = {fmaf(kS2, db.re, kS1 * da.re), fmaf(kS2, db.im, kS1 * da.im)};
+    const c32 b2 = {fmaf(-kS1, db.re, kS2 * da.re), fmaf(-kS1, db.im, kS2 * da.im)};
+    // y1 = a1 - i b1, y4 = a1 + i b1, y2 = a2 - i b2, y3 = a2 + i b2
+    y1 = {a1.re + b1.im, a1.im - b1.re};
+    y4 = {a1.re - b1.im, a1.im + b1.re};
+    y2 = {a2.re + b2.im, a2.im - b2.re};
+    y3 = {a2.re - b2.im, a2.im + b2.re};
+}
+// radix-4 butterfly, forward transform (W4 = -i)
+__device__ __forceinline__ void bfly4(c32 v0, c32 v1, c32 v2, c32 v3, c32& r0, c32& r1, c32& r2, c32& r3) {
+    const c32 e0 = v0 + v2, e1 = v0 - v2, o0 = v1 + v3, o1 = v1 - v3;
+    r0 = e0 + o0;
+    r2 = e0 - o0;
+    r1 = {e1.re + o1.im, e1.im - o1.re};
+    r3 = {e1.re - o1.im, e1.im + o1.re};
+}
+
+// W25^e = cos - i sin, e = b c for b = 1..4, c = 1,2
+constexpr float kW25c[9] = {1.f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899666f,
+                            0.f, 0.06279051952931353f, 0.f, -0.42577929156507272f};
+constexpr float kW25s[9] = {0.f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868873f, 0.84432792550201508f,
+                            0.f, 0.99802672842827156f, 0.f, 0.90482705246601958f};
+constexpr float kR2 = 0.70710678118654752f;                                     // 1/sqrt 2
+constexpr float kW16c1 = 0.92387953251128674f, kW16s1 = 0.38268343236508977f;   // cos, sin (pi/8)
+
+constexpr int kRowBytes = 128;                 // one (k1, frame) row: 16 complex values over n2
+constexpr int kPlaneBytes = 16 * kRowBytes;    // one k1: 16 frames
+constexpr int kFftLds = 13 * kPlaneBytes;      // 26,624 B per wave: six workgroups per CU
+
+}  // namespace
+
+// MT = mel tiles of 16 filters.  One workgroup = one wave = 16 frames of the flattened [B*T] frame index.
+template <int MT>
+__global__ void __launch_bounds__(64) mel_fft400_kernel(const FrontendParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[kFftLds];
+    const int lane = threadIdx.x;
+    const int hi = lane >> 4, lo = lane & 15;          // stage 1: (frame j of 4, n2); stage 2 / MFMA: (g, frame f of 16)
+    const long long total = (long long)p.B * p.T;
+    const long long f0 = (long long)blockIdx.x * 16;
+
+    // ---- stage 1: four rounds of four frames ----
+    {
+        const int n2 = lo;
+        // W400^{n2 k1}, k1 = 1..12, for this lane's n2 (cos, sin): [12][16] float2
+        float twc[12], tws[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const float2 t = reinterpret_cast<const float2*>(p.dft)[k * 16 + n2];
+            twc[k] = t.x;
+            tws[k] = t.y;
+        }
+        long long fidx = f0 + hi;
+        fidx = fidx < total ? fidx : total - 1;         // frames past the end redo the last one (finite values, never stored)
+        long long sb = fidx / p.T;
+        int st = (int)(fidx - sb * p.T);
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int f = 4 * i + hi;
+            // the signal of stream sb is carry[sb] (n_carry samples, may be 0) followed by pcm[sb] (detector.py:179)
+            const float* xc_ = p.carry + (size_t)sb * p.n_carry;
+            const float* xp_ = p.pcm + (size_t)sb * (p.n_samples - p.n_carry);
+            const int s0 = st * p.hop + n2;
+            float x[25];
+            const bool seam = s0 - n2 < p.n_carry && s0 - n2 + 400 > p.n_carry;
+            if (!__builtin_amdgcn_ballot_w64(seam)) {
+                const float* src = s0 - n2 >= p.n_carry ? xp_ + (s0 - p.n_carry) : xc_ + s0;
+#pragma unroll
+                for (int n1 = 0; n1 < 25; ++n1) x[n1] = src[16 * n1];
+            } else {
+                // some frame of this round straddles the seam (the first two or three frames of a chunk): per-sample select
+#pragma unroll
+                for (int n1 = 0; n1 < 25; ++n1) {
+                    const int idx = s0 + 16 * n1;
+                    const float* src = idx < p.n_carry ? xc_ + idx : xp_ + (idx - p.n_carry);
+                    x[n1] = *src;
+                }
+            }
+            // next round's frame: four frames on (wraps into the following streams; T may be smaller than 4)
+            {
+                long long nf = f0 + f + 4;
+                if (nf < total) {
+                    st += 4;
+                    while (st >= p.T) { st -= p.T; ++sb; }
+                }
+            }
+            // Z_b[c] = sum_a x[5a + b] W5^{ac}
+            float z0[5];
+            c32 z1[5], z2[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) rdft5(x[b], x[5 + b], x[10 + b], x[15 + b], x[20 + b], z0[b], z1[b], z2[b]);
+            c32 Y[13];
+            {   // c = 0: real inputs again
+                float y0;
+                rdft5(z0[0], z0[1], z0[2], z0[3], z0[4], y0, Y[5], Y[10]);
+                Y[0] = {y0, 0.f};
+            }
+            {   // c = 1: Y1, Y6, Y11, Y16, Y21
+                c32 y16, y21;
+                cdft5(z1[0], cmul(z1[1], kW25c[1], -kW25s[1]), cmul(z1[2], kW25c[2], -kW25s[2]), cmul(z1[3], kW25c[3], -kW25s[3]),
+                      cmul(z1[4], kW25c[4], -kW25s[4]), Y[1], Y[6], Y[11], y16, y21);
+                Y[9] = conj(y16);
+                Y[4] = conj(y21);
+            }
+            {   // c = 2: Y2, Y7, Y12, Y17, Y22
+                c32 y17, y22;
+                cdft5(z2[0], cmul(z2[1], kW25c[2], -kW25s[2]), cmul(z2[2], kW25c[4], -kW25s[4]), cmul(z2[3], kW25c[6], -kW25s[6]),
+                      cmul(z2[4], kW25c[8], -kW25s[8]), Y[2], Y[7], Y[12], y17, y22);
+                Y[8] = conj(y17);
+                Y[3] = conj(y22);
+            }
+            // twiddle W400^{n2 k1} and park the row: plane k1, row f, column n2 ^ (f & 14) (the swizzle that makes the
+            // stage-2 ds_read_b128 of sixteen different rows conflict-free)
+            char* dst = lds + f * kRowBytes + ((n2 ^ (f & 14)) << 3);
+            *reinterpret_cast<float2*>(dst) = make_float2(Y[0].re, Y[0].im);
+#pragma unroll
+            for (int k1 = 1; k1 < 13; ++k1) {
+                const c32 t = cmul(Y[k1], twc[k1 - 1], -tws[k1 - 1]);
+                *reinterpret_cast<float2*>(dst + k1 * kPlaneBytes) = make_float2(t.re, t.im);
+            }
+        }
+    }
+    __syncthreads();      // one wave: orders the LDS writes above against the reads below
+
+    // ---- stage 2 + mel projection ----
+    const int g = hi, f = lo;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = splat4(0.f);
+    const int sf = (f >> 1) & 7;
+    const float* melA = p.melw + lane;                  // [4 passes][16 k2][MT][64 lanes]
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        // basis fragments of this pass first: their latency hides behind the FFT
+        float a[16][MT];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[k2][m] = melA[((q * 16 + k2) * MT + m) * 64];
+        const int k1 = 4 * q + g < 12 ? 4 * q + g : 12;         // lanes past k1 = 12 re-read plane 12 against zero weights
+        const char* row = lds + k1 * kPlaneBytes + f * kRowBytes;
+        c32 z[16];
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + ((pr ^ sf) << 4));
+            z[2 * pr] = {v[0], v[1]};
+            z[2 * pr + 1] = {v[2], v[3]};
+        }
+        // 16-point FFT, n2 = 4a + b, k2 = c + 4d
+        c32 u[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bfly4(z[b], z[4 + b], z[8 + b], z[12 + b], u[b][0], u[b][1], u[b][2], u[b][3]);
+        c32 o[16];
+        bfly4(u[0][0], u[1][0], u[2][0], u[3][0], o[0], o[4], o[8], o[12]);
+        {   // c = 1: W16^1, W16^2, W16^3
+            const c32 v1 = cmul(u[1][1], kW16c1, -kW16s1);
+            const c32 v2 = {(u[2][1].re + u[2][1].im) * kR2, (u[2][1].im - u[2][1].re) * kR2};
+            const c32 v3 = cmul(u[3][1], kW16s1, -kW16c1);
+            bfly4(u[0][1], v1, v2, v3, o[1], o[5], o[9], o[13]);
+        }
+        {   // c = 2: W16^2, W16^4 = -i, W16^6
+            const c32 v1 = {(u[1][2].re + u[1][2].im) * kR2, (u[1][2].im - u[1][2].re) * kR2};
+            const c32 v2 = {u[2][2].im, -u[2][2].re};
+            const c32 v3 = {(u[3][2].im - u[3][2].re) * kR2, -(u[3][2].re + u[3][2].im) * kR2};
+            bfly4(u[0][2], v1, v2, v3, o[2], o[6], o[10], o[14]);
+        }
+        {   // c = 3: W16^3, W16^6, W16^9 = -W16^1
+            const c32 v1 = cmul(u[1][3], kW16s1, -kW16c1);
+            const c32 v2 = {(u[2][3].im - u[2][3].re) * kR2, -(u[2][3].re + u[2][3].im) * kR2};
+            const c32 v3 = cmul(u[3][3], -kW16c1, kW16s1);
+            bfly4(u[0][3], v1, v2, v3, o[3], o[7], o[11], o[15]);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const float mag = __builtin_amdgcn_sqrtf(fmaf(o[k2].re, o[k2].re, o[k2].im * o[k2].im));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = mfma4(a[k2][m], mag, acc[m]);
+        }
+    }
+    // D[filter 16m + 4g + e][frame f]
+    const long long fo = f0 + f;
+    if (fo < total) {
+        float* out = p.mel + (size_t)fo * p.n_mel;
+        const bool vec = (p.n_mel & 3) == 0 && (reinterpret_cast<uintptr_t>(p.mel) & 15) == 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int c0 = 16 * m + 4 * g;
+            if (vec) {
+                if (c0 < p.n_mel) *reinterpret_cast<f32x4*>(out + c0) = acc[m];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < p.n_mel) out[c0 + e] = acc[m][e];
+            }
+        }
+    }
+}
+
+hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st) {
+    const long long total = (long long)B * p.T;
+    const unsigned grid = (unsigned)((total + 15) / 16);
+    switch (p.mel_tiles) {
+        case 1: hipLaunchKernelGGL(mel_fft400_kernel<1>, dim3(grid), dim3(64), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(mel_fft400_kernel<2>, dim3(grid), dim3(64), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(mel_fft400_kernel<3>, dim3(grid), dim3(64), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(mel_fft400_kernel<4>, dim3(grid), dim3(64), 0, st, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace kws

@@ -121,6 +121,8 @@ struct kws_frontend {
     kws_frontend_config cfg;
     float* d_tables = nullptr;
     size_t dft_off = 0, melw_off = 0;
+    size_t fft_tw_off = 0, fft_mel_off = 0;   // fft_frontend.hip tables (fft_size 400 only)
+    bool use_fft = false;
     int nf_tiles = 0, mel_tiles = 0, kc4 = 0;
     std::vector<float> basis;      // [n_mel][fft/2+1]
 };
@@ -1051,6 +1053,33 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
                         }
                         host[f->melw_off + ((((size_t)mt * TILES + t) * 2 + mir) * 4 + e) * 64 + lane] = v;
                     }
+    if (N == 400) {
+        // fft_frontend.hip: the 16 x 25 real FFT.  Twiddles W400^{n2 k1} as (cos, sin) [k1 = 1..12][n2 = 0..15]; basis fragments in
+        // the order its stage 2 leaves the magnitudes in registers: pass q, k2, mel tile -> lane (g, i) holds
+        // basis[16 tile + i][bin(k1 = 4q + g, k2)], bin = k1 + 25 k2 folded at 200; slots that exist twice or not at all are zero.
+        f->fft_tw_off = host.size();
+        host.resize(host.size() + 12 * 16 * 2, 0.f);
+        for (int k1 = 1; k1 <= 12; ++k1)
+            for (int n2 = 0; n2 < 16; ++n2) {
+                const double ang = two_pi * (double)(n2 * k1) / 400.0;
+                host[f->fft_tw_off + ((size_t)(k1 - 1) * 16 + n2) * 2 + 0] = (float)std::cos(ang);
+                host[f->fft_tw_off + ((size_t)(k1 - 1) * 16 + n2) * 2 + 1] = (float)std::sin(ang);
+            }
+        f->fft_mel_off = host.size();
+        const int MT = f->mel_tiles;
+        host.resize(host.size() + (size_t)4 * 16 * MT * 64, 0.f);
+        for (int q = 0; q < 4; ++q)
+            for (int k2 = 0; k2 < 16; ++k2)
+                for (int mt = 0; mt < MT; ++mt)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 4, i = lane & 15, k1 = 4 * q + g, m = 16 * mt + i, k = k1 + 25 * k2;
+                        float v = 0.f;
+                        if (k1 <= 12 && m < cfg->n_mel && !(k1 == 0 && k2 >= 9)) v = f->basis[(size_t)m * NF + (k <= 200 ? k : 400 - k)];
+                        host[f->fft_mel_off + (((size_t)(q * 16 + k2) * MT + mt) * 64) + lane] = v;
+                    }
+        const char* dense = getenv("KWS_FRONTEND_DENSE");      // A/B switch: the dense-DFT kernel also handles 400
+        f->use_fft = !(dense && dense[0] == '1');
+    }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->d_tables), host.size() * sizeof(float));
     if (e != hipSuccess) { delete f; return hip_fail(e, "hipMalloc(frontend tables)"); }
     e = hipMemcpy(f->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -1086,7 +1115,13 @@ static int frontend_run_impl(kws_frontend_handle h, const float* carry, int n_ca
     p.dft = h->d_tables + h->dft_off; p.melw = h->d_tables + h->melw_off;
     p.n_samples = n_samples; p.n_carry = n_carry; p.T = T; p.fft = h->cfg.fft_size; p.hop = h->cfg.hop_size; p.n_mel = h->cfg.n_mel;
     p.nf_tiles = h->nf_tiles; p.mel_tiles = h->mel_tiles; p.kc4 = h->kc4; p.B = B;
-    hipError_t e = kws::launch_mel_frontend(p, B, static_cast<hipStream_t>(stream));
+    hipError_t e;
+    if (h->use_fft && (long long)B * T < (1LL << 31)) {
+        p.dft = h->d_tables + h->fft_tw_off; p.melw = h->d_tables + h->fft_mel_off;
+        e = kws::launch_mel_fft400(p, B, static_cast<hipStream_t>(stream));
+    } else {
+        e = kws::launch_mel_frontend(p, B, static_cast<hipStream_t>(stream));
+    }
     if (e != hipSuccess) return hip_fail(e, "launch mel_frontend");
     return KWS_OK;
 }

@@ -156,6 +156,8 @@ struct FrontendParams {
     int n_samples, T, fft, hop, n_mel, nf_tiles, mel_tiles, kc4, B, n_carry;   // n_samples = n_carry + new samples
 };
 hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st);
+// fft 400 only (fft_frontend.hip): p.dft = twiddles [12][16] (cos, sin), p.melw = basis fragments [4][16][mel_tiles][64]
+hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st);
 hipError_t launch_carry_tail(const float* carry, int n_carry, const float* chunk, int n_chunk, float* next, int n_next, int B,
                              hipStream_t st);
 

@@ -30,4 +30,4 @@ mkdir -p $OUT/commit
 cp $OUT/summary.txt $OUT/commit/${TAG}_rocprofv3_summary.txt
 cp $OUT/pmc.json $OUT/commit/${TAG}_pmc.json
 cp $OUT/trace/*kernel_stats.csv $OUT/commit/${TAG}_kernel_stats.csv 2>/dev/null
-tail -1 $OUT/trace_bench.log > $OUT/commit/${TAG}_bench_under_trace.json
+grep "^{" $OUT/trace_bench.log | tail -1 > $OUT/commit/${TAG}_bench_under_trace.json
