@@ -13,9 +13,8 @@
 // Stage 2: for k1 = 0..12 a 16-point complex FFT over n2 (radix 4 x 4) gives X[k1 + 25 k2], k2 = 0..15.  Those 208 values
 //   hold every bin 0..200 exactly once: k <= 200 directly, k > 200 as the mirror 400 - k (|X[400-k]| = |X[k]|; the bins of
 //   residue 13..24 mod 25), and k1 = 0, k2 >= 9 are duplicates that the mel table zeroes.
-// Between the stages the 13 x 16 complex values of a frame cross lanes through LDS (one transpose, wave-private: a
-// workgroup is ONE wave = 16 frames, no barrier anywhere).  In stage 2 lane = (g, frame f of 16) takes k1 = 4q + g in pass
-// q, so its sixteen magnitudes are -- as they stand in registers -- the B operands (k = g, n = f) of the mel projection on
+// Between the stages the 13 x 16 complex values of a frame cross lanes through LDS (one transpose; a workgroup is 16 frames).
+// In stage 2 lane = (g, frame f of 16) takes k1 = 4q + g in pass q (= wave q), so its sixteen magnitudes are -- as they stand in registers -- the B operands (k = g, n = f) of the mel projection on
 // v_mfma_f32_16x16x4_f32; the order of the bins along K is free, the basis fragments are packed to match (kws_api.hip).
 // ~9 kflop per frame on the VALU instead of the 100 kflop of the dense contraction.
 #include "gru_device.h"
@@ -79,118 +78,113 @@ constexpr float kW16c1 = 0.92387953251128674f, kW16s1 = 0.38268343236508977f;   
 
 constexpr int kRowBytes = 128;                 // one (k1, frame) row: 16 complex values over n2
 constexpr int kPlaneBytes = 16 * kRowBytes;    // one k1: 16 frames
-constexpr int kFftLds = 13 * kPlaneBytes;      // 26,624 B per wave: six workgroups per CU
+constexpr int kFftLds = 13 * kPlaneBytes;      // 26,624 B per workgroup: six workgroups per CU
+constexpr int kSpecRows = 208;                 // spectrum rows (bins 0..200 + zero padding) of 16 frames: 13,312 B of the same space
 
 }  // namespace
 
-// MT = mel tiles of 16 filters.  One workgroup = one wave = 16 frames of the flattened [B*T] frame index.
+// MT = mel tiles of 16 filters.  One workgroup = 4 waves = 16 frames of the flattened [B*T] frame index: wave w runs
+// stage 1 for frames 4w..4w+3, after the barrier stage 2 for k1 = 4w..4w+3 of all sixteen frames, and the magnitudes go
+// back to LDS in BIN order (S[bin][frame]) so that the mel projection only touches the 4-bin x 16-filter blocks whose
+// weights are not all zero: filters are contiguous in frequency, so tile m needs one contiguous run of 4-bin groups --
+// 52 MFMAs per 16 frames for 40 filters where the dense product takes 156.  Wave m = tile m.
+// 26 KiB of LDS per workgroup (the spectrum reuses the transpose planes): six workgroups = 24 waves per CU.
 template <int MT>
-__global__ void __launch_bounds__(64) mel_fft400_kernel(const FrontendParams p) {
+__global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams p) {
     __shared__ __attribute__((aligned(16))) char lds[kFftLds];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int hi = lane >> 4, lo = lane & 15;          // stage 1: (frame j of 4, n2); stage 2 / MFMA: (g, frame f of 16)
-    const long long total = (long long)p.B * p.T;
-    const long long f0 = (long long)blockIdx.x * 16;
+    const unsigned total = (unsigned)p.B * (unsigned)p.T;
+    const unsigned f0 = blockIdx.x * 16u;
+#ifdef KWS_FE_TIMING       // tools/ubench/fe_phases.hip: s_memtime at the phase boundaries of every wave
+#define KWS_FE_STAMP(i) do { if (lane == 0) p.timing[((size_t)blockIdx.x * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define KWS_FE_STAMP(i) do {} while (0)
+#endif
+    KWS_FE_STAMP(0);
 
-    // ---- stage 1: four rounds of four frames ----
+    // ---- stage 1: this wave's four frames ----
     {
         const int n2 = lo;
-        // W400^{n2 k1}, k1 = 1..12, for this lane's n2 (cos, sin): [12][16] float2
-        float twc[12], tws[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const float2 t = reinterpret_cast<const float2*>(p.dft)[k * 16 + n2];
-            twc[k] = t.x;
-            tws[k] = t.y;
-        }
-        long long fidx = f0 + hi;
+        const int f = 4 * w + hi;
+        unsigned fidx = f0 + f;
         fidx = fidx < total ? fidx : total - 1;         // frames past the end redo the last one (finite values, never stored)
-        long long sb = fidx / p.T;
-        int st = (int)(fidx - sb * p.T);
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-            const int f = 4 * i + hi;
-            // the signal of stream sb is carry[sb] (n_carry samples, may be 0) followed by pcm[sb] (detector.py:179)
-            const float* xc_ = p.carry + (size_t)sb * p.n_carry;
-            const float* xp_ = p.pcm + (size_t)sb * (p.n_samples - p.n_carry);
-            const int s0 = st * p.hop + n2;
-            float x[25];
-            const bool seam = s0 - n2 < p.n_carry && s0 - n2 + 400 > p.n_carry;
-            if (!__builtin_amdgcn_ballot_w64(seam)) {
-                const float* src = s0 - n2 >= p.n_carry ? xp_ + (s0 - p.n_carry) : xc_ + s0;
+        const unsigned sb = fidx / (unsigned)p.T;
+        const int st = (int)(fidx - sb * (unsigned)p.T);
+        // the signal of stream sb is carry[sb] (n_carry samples, may be 0) followed by pcm[sb] (detector.py:179)
+        const float* xc_ = p.carry + (size_t)sb * p.n_carry;
+        const float* xp_ = p.pcm + (size_t)sb * (p.n_samples - p.n_carry);
+        const int s0 = st * p.hop + n2;
+        float x[25];
+        const bool seam = s0 - n2 < p.n_carry && s0 - n2 + 400 > p.n_carry;
+        if (!__builtin_amdgcn_ballot_w64(seam)) {
+            const float* src = s0 - n2 >= p.n_carry ? xp_ + (s0 - p.n_carry) : xc_ + s0;
 #pragma unroll
-                for (int n1 = 0; n1 < 25; ++n1) x[n1] = src[16 * n1];
-            } else {
-                // some frame of this round straddles the seam (the first two or three frames of a chunk): per-sample select
+            for (int n1 = 0; n1 < 25; ++n1) x[n1] = src[16 * n1];
+        } else {
+            // some frame of this wave straddles the seam (the first two or three frames of a chunk): per-sample select
 #pragma unroll
-                for (int n1 = 0; n1 < 25; ++n1) {
-                    const int idx = s0 + 16 * n1;
-                    const float* src = idx < p.n_carry ? xc_ + idx : xp_ + (idx - p.n_carry);
-                    x[n1] = *src;
-                }
+            for (int n1 = 0; n1 < 25; ++n1) {
+                const int idx = s0 + 16 * n1;
+                const float* src = idx < p.n_carry ? xc_ + idx : xp_ + (idx - p.n_carry);
+                x[n1] = *src;
             }
-            // next round's frame: four frames on (wraps into the following streams; T may be smaller than 4)
-            {
-                long long nf = f0 + f + 4;
-                if (nf < total) {
-                    st += 4;
-                    while (st >= p.T) { st -= p.T; ++sb; }
-                }
-            }
-            // Z_b[c] = sum_a x[5a + b] W5^{ac}
-            float z0[5];
-            c32 z1[5], z2[5];
+        }
+        // W400^{n2 k1}, k1 = 1..12, for this lane's n2 (cos, sin): [12][16] float2
+        float2 tw[12];
 #pragma unroll
-            for (int b = 0; b < 5; ++b) rdft5(x[b], x[5 + b], x[10 + b], x[15 + b], x[20 + b], z0[b], z1[b], z2[b]);
-            c32 Y[13];
-            {   // c = 0: real inputs again
-                float y0;
-                rdft5(z0[0], z0[1], z0[2], z0[3], z0[4], y0, Y[5], Y[10]);
-                Y[0] = {y0, 0.f};
-            }
-            {   // c = 1: Y1, Y6, Y11, Y16, Y21
-                c32 y16, y21;
-                cdft5(z1[0], cmul(z1[1], kW25c[1], -kW25s[1]), cmul(z1[2], kW25c[2], -kW25s[2]), cmul(z1[3], kW25c[3], -kW25s[3]),
-                      cmul(z1[4], kW25c[4], -kW25s[4]), Y[1], Y[6], Y[11], y16, y21);
-                Y[9] = conj(y16);
-                Y[4] = conj(y21);
-            }
-            {   // c = 2: Y2, Y7, Y12, Y17, Y22
-                c32 y17, y22;
-                cdft5(z2[0], cmul(z2[1], kW25c[2], -kW25s[2]), cmul(z2[2], kW25c[4], -kW25s[4]), cmul(z2[3], kW25c[6], -kW25s[6]),
-                      cmul(z2[4], kW25c[8], -kW25s[8]), Y[2], Y[7], Y[12], y17, y22);
-                Y[8] = conj(y17);
-                Y[3] = conj(y22);
-            }
-            // twiddle W400^{n2 k1} and park the row: plane k1, row f, column n2 ^ (f & 14) (the swizzle that makes the
-            // stage-2 ds_read_b128 of sixteen different rows conflict-free)
-            char* dst = lds + f * kRowBytes + ((n2 ^ (f & 14)) << 3);
-            *reinterpret_cast<float2*>(dst) = make_float2(Y[0].re, Y[0].im);
+        for (int k = 0; k < 12; ++k) tw[k] = reinterpret_cast<const float2*>(p.dft)[k * 16 + n2];
+#ifdef KWS_FE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KWS_FE_STAMP(1);
+#endif
+        // Z_b[c] = sum_a x[5a + b] W5^{ac}
+        float z0[5];
+        c32 z1[5], z2[5];
 #pragma unroll
-            for (int k1 = 1; k1 < 13; ++k1) {
-                const c32 t = cmul(Y[k1], twc[k1 - 1], -tws[k1 - 1]);
-                *reinterpret_cast<float2*>(dst + k1 * kPlaneBytes) = make_float2(t.re, t.im);
-            }
+        for (int b = 0; b < 5; ++b) rdft5(x[b], x[5 + b], x[10 + b], x[15 + b], x[20 + b], z0[b], z1[b], z2[b]);
+        c32 Y[13];
+        {   // c = 0: real inputs again
+            float y0;
+            rdft5(z0[0], z0[1], z0[2], z0[3], z0[4], y0, Y[5], Y[10]);
+            Y[0] = {y0, 0.f};
+        }
+        {   // c = 1: Y1, Y6, Y11, Y16, Y21
+            c32 y16, y21;
+            cdft5(z1[0], cmul(z1[1], kW25c[1], -kW25s[1]), cmul(z1[2], kW25c[2], -kW25s[2]), cmul(z1[3], kW25c[3], -kW25s[3]),
+                  cmul(z1[4], kW25c[4], -kW25s[4]), Y[1], Y[6], Y[11], y16, y21);
+            Y[9] = conj(y16);
+            Y[4] = conj(y21);
+        }
+        {   // c = 2: Y2, Y7, Y12, Y17, Y22
+            c32 y17, y22;
+            cdft5(z2[0], cmul(z2[1], kW25c[2], -kW25s[2]), cmul(z2[2], kW25c[4], -kW25s[4]), cmul(z2[3], kW25c[6], -kW25s[6]),
+                  cmul(z2[4], kW25c[8], -kW25s[8]), Y[2], Y[7], Y[12], y17, y22);
+            Y[8] = conj(y17);
+            Y[3] = conj(y22);
+        }
+        // twiddle W400^{n2 k1} and park the row: plane k1, row f, column n2 ^ (f & 14) (the swizzle that makes the
+        // stage-2 ds_read_b128 of sixteen different rows conflict-free)
+        char* dst = lds + f * kRowBytes + ((n2 ^ (f & 14)) << 3);
+        *reinterpret_cast<float2*>(dst) = make_float2(Y[0].re, Y[0].im);
+#pragma unroll
+        for (int k1 = 1; k1 < 13; ++k1) {
+            const c32 t = cmul(Y[k1], tw[k1 - 1].x, -tw[k1 - 1].y);
+            *reinterpret_cast<float2*>(dst + k1 * kPlaneBytes) = make_float2(t.re, t.im);
         }
     }
-    __syncthreads();      // one wave: orders the LDS writes above against the reads below
+    KWS_FE_STAMP(2);
+    __syncthreads();
+    KWS_FE_STAMP(3);
 
-    // ---- stage 2 + mel projection ----
-    const int g = hi, f = lo;
-    f32x4 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = splat4(0.f);
-    const int sf = (f >> 1) & 7;
-    const float* melA = p.melw + lane;                  // [4 passes][16 k2][MT][64 lanes]
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        // basis fragments of this pass first: their latency hides behind the FFT
-        float a[16][MT];
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a[k2][m] = melA[((q * 16 + k2) * MT + m) * 64];
-        const int k1 = 4 * q + g < 12 ? 4 * q + g : 12;         // lanes past k1 = 12 re-read plane 12 against zero weights
+    // ---- stage 2: pass q = w, k1 = 4w + g ----
+    const int g = hi, f = lo, q = w;
+    float mag[16];
+    {
+        const int k1 = 4 * q + g < 12 ? 4 * q + g : 12;         // lanes past k1 = 12 recompute plane 12 and store nothing
+        const int sf = (f >> 1) & 7;
         const char* row = lds + k1 * kPlaneBytes + f * kRowBytes;
         c32 z[16];
 #pragma unroll
@@ -224,39 +218,89 @@ __global__ void __launch_bounds__(64) mel_fft400_kernel(const FrontendParams p) 
             bfly4(u[0][3], v1, v2, v3, o[3], o[7], o[11], o[15]);
         }
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-            const float mag = __builtin_amdgcn_sqrtf(fmaf(o[k2].re, o[k2].re, o[k2].im * o[k2].im));
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = mfma4(a[k2][m], mag, acc[m]);
-        }
+        for (int k2 = 0; k2 < 16; ++k2) mag[k2] = __builtin_amdgcn_sqrtf(fmaf(o[k2].re, o[k2].re, o[k2].im * o[k2].im));
     }
-    // D[filter 16m + 4g + e][frame f]
-    const long long fo = f0 + f;
-    if (fo < total) {
-        float* out = p.mel + (size_t)fo * p.n_mel;
-        const bool vec = (p.n_mel & 3) == 0 && (reinterpret_cast<uintptr_t>(p.mel) & 15) == 0;
+    // basis fragments of this wave's mel tile: the first kMelRegs groups of its run wait in registers (the loads fly while the
+    // spectrum is written and the workgroup meets at the barrier); a longer run streams the rest
+    constexpr int kMelRegs = 24;
+    const int lo4 = w < MT ? p.mel_lo[w] : 0, n = w < MT ? p.mel_cnt[w] : 0;   // first 4-bin group, number of groups (multiple of 4; zero-padded table)
+    const float* A = p.melw + ((size_t)(w < MT ? p.mel_off[w] : 0) * 64 + lane);
+    float a[kMelRegs];
+    if (n > 0) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int c0 = 16 * m + 4 * g;
-            if (vec) {
-                if (c0 < p.n_mel) *reinterpret_cast<f32x4*>(out + c0) = acc[m];
+        for (int e = 0; e < kMelRegs; ++e) a[e] = A[(size_t)(e < n ? e : n - 1) * 64];
+    }
+    KWS_FE_STAMP(4);
+    lds_barrier();             // every wave has read its planes: the spectrum takes their place
+    KWS_FE_STAMP(5);
+    // ---- |X| in bin order: S[bin][frame], 64 B rows.  bin = k1 + 25 k2 folded at 200 ----
+    float* S = reinterpret_cast<float*>(lds);
+    {
+        const int k1 = 4 * q + g;
+        if (k1 <= 12) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) S[(k1 + 25 * k2) * 16 + f] = mag[k2];
+            if (k1 == 0) {
+                S[200 * 16 + f] = mag[8];
+            } else {
+#pragma unroll
+                for (int k2 = 8; k2 < 16; ++k2) S[(400 - 25 * k2 - k1) * 16 + f] = mag[k2];
+            }
+        }
+        if (tid < 16 * (kSpecRows - 201)) S[201 * 16 + tid] = 0.f;     // padding rows the last block may read
+    }
+    lds_barrier();
+    KWS_FE_STAMP(6);
+
+    // ---- mel projection: wave m = mel tile m over its contiguous run of 4-bin groups.  A = basis fragments
+    // [tile][group][64 lanes], B = four spectrum rows (k = g) x 16 frames; two accumulators break the dependent chain ----
+    if (n > 0) {
+        const float* Sg = S + lo4 * 64 + lane;
+        f32x4 acc0 = splat4(0.f), acc1 = splat4(0.f);
+        // runs are padded to multiples of four groups: four spectrum reads in flight, then four MFMAs
+        static_for<0, kMelRegs / 4>([&](auto c) {
+            constexpr int e0 = 4 * decltype(c)::value;
+            if (e0 < n) {
+                const float b0 = Sg[e0 * 64], b1 = Sg[(e0 + 1) * 64], b2 = Sg[(e0 + 2) * 64], b3 = Sg[(e0 + 3) * 64];
+                acc0 = mfma4(a[e0], b0, acc0);
+                acc1 = mfma4(a[e0 + 1], b1, acc1);
+                acc0 = mfma4(a[e0 + 2], b2, acc0);
+                acc1 = mfma4(a[e0 + 3], b3, acc1);
+            }
+        });
+        for (int e = kMelRegs; e < n; e += 4) {
+            const float b0 = Sg[e * 64], b1 = Sg[(e + 1) * 64], b2 = Sg[(e + 2) * 64], b3 = Sg[(e + 3) * 64];
+            acc0 = mfma4(A[(size_t)e * 64], b0, acc0);
+            acc1 = mfma4(A[(size_t)(e + 1) * 64], b1, acc1);
+            acc0 = mfma4(A[(size_t)(e + 2) * 64], b2, acc0);
+            acc1 = mfma4(A[(size_t)(e + 3) * 64], b3, acc1);
+        }
+        const f32x4 r = acc0 + acc1;
+        // D[filter 16w + 4g + e][frame f]
+        const unsigned fo = f0 + f;
+        if (fo < total) {
+            float* out = p.mel + (size_t)fo * p.n_mel;
+            const int c0 = 16 * w + 4 * g;
+            if ((p.n_mel & 3) == 0 && (reinterpret_cast<uintptr_t>(p.mel) & 15) == 0) {
+                if (c0 < p.n_mel) *reinterpret_cast<f32x4*>(out + c0) = r;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (c0 + e < p.n_mel) out[c0 + e] = acc[m][e];
+                    if (c0 + e < p.n_mel) out[c0 + e] = r[e];
             }
         }
     }
+    KWS_FE_STAMP(7);
 }
 
 hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st) {
-    const long long total = (long long)B * p.T;
+    const long long total = (long long)B * p.T;        // < 2^31 (checked by the caller)
     const unsigned grid = (unsigned)((total + 15) / 16);
     switch (p.mel_tiles) {
-        case 1: hipLaunchKernelGGL(mel_fft400_kernel<1>, dim3(grid), dim3(64), 0, st, p); break;
-        case 2: hipLaunchKernelGGL(mel_fft400_kernel<2>, dim3(grid), dim3(64), 0, st, p); break;
-        case 3: hipLaunchKernelGGL(mel_fft400_kernel<3>, dim3(grid), dim3(64), 0, st, p); break;
-        case 4: hipLaunchKernelGGL(mel_fft400_kernel<4>, dim3(grid), dim3(64), 0, st, p); break;
+        case 1: hipLaunchKernelGGL(mel_fft400_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(mel_fft400_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(mel_fft400_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(mel_fft400_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

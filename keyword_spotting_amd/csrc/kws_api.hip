@@ -122,6 +122,7 @@ struct kws_frontend {
     float* d_tables = nullptr;
     size_t dft_off = 0, melw_off = 0;
     size_t fft_tw_off = 0, fft_mel_off = 0;   // fft_frontend.hip tables (fft_size 400 only)
+    int mel_lo[4] = {0, 0, 0, 0}, mel_cnt[4] = {0, 0, 0, 0}, mel_off[4] = {0, 0, 0, 0};
     bool use_fft = false;
     int nf_tiles = 0, mel_tiles = 0, kc4 = 0;
     std::vector<float> basis;      // [n_mel][fft/2+1]
@@ -1054,9 +1055,9 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
                         host[f->melw_off + ((((size_t)mt * TILES + t) * 2 + mir) * 4 + e) * 64 + lane] = v;
                     }
     if (N == 400) {
-        // fft_frontend.hip: the 16 x 25 real FFT.  Twiddles W400^{n2 k1} as (cos, sin) [k1 = 1..12][n2 = 0..15]; basis fragments in
-        // the order its stage 2 leaves the magnitudes in registers: pass q, k2, mel tile -> lane (g, i) holds
-        // basis[16 tile + i][bin(k1 = 4q + g, k2)], bin = k1 + 25 k2 folded at 200; slots that exist twice or not at all are zero.
+        // fft_frontend.hip: the 16 x 25 real FFT.  Twiddles W400^{n2 k1} as (cos, sin) [k1 = 1..12][n2 = 0..15].  Mel basis as MFMA
+        // A fragments over 4-bin groups (k = g <-> bin 4 group + g): per tile of 16 filters only the contiguous run of groups that
+        // carry a non-zero weight, padded to a multiple of four; bins > 200 are zero rows.
         f->fft_tw_off = host.size();
         host.resize(host.size() + 12 * 16 * 2, 0.f);
         for (int k1 = 1; k1 <= 12; ++k1)
@@ -1066,17 +1067,26 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
                 host[f->fft_tw_off + ((size_t)(k1 - 1) * 16 + n2) * 2 + 1] = (float)std::sin(ang);
             }
         f->fft_mel_off = host.size();
-        const int MT = f->mel_tiles;
-        host.resize(host.size() + (size_t)4 * 16 * MT * 64, 0.f);
-        for (int q = 0; q < 4; ++q)
-            for (int k2 = 0; k2 < 16; ++k2)
-                for (int mt = 0; mt < MT; ++mt)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int g = lane >> 4, i = lane & 15, k1 = 4 * q + g, m = 16 * mt + i, k = k1 + 25 * k2;
-                        float v = 0.f;
-                        if (k1 <= 12 && m < cfg->n_mel && !(k1 == 0 && k2 >= 9)) v = f->basis[(size_t)m * NF + (k <= 200 ? k : 400 - k)];
-                        host[f->fft_mel_off + (((size_t)(q * 16 + k2) * MT + mt) * 64) + lane] = v;
-                    }
+        int groups_total = 0;
+        for (int mt = 0; mt < f->mel_tiles; ++mt) {
+            int lo = 51, hi = -1;                       // 51 groups cover bins 0..203
+            for (int grp = 0; grp < 51; ++grp)
+                for (int b = 4 * grp; b < 4 * grp + 4 && b <= 200; ++b)
+                    for (int m = 16 * mt; m < 16 * mt + 16 && m < cfg->n_mel; ++m)
+                        if (f->basis[(size_t)m * NF + b] != 0.f) { lo = std::min(lo, grp); hi = std::max(hi, grp); }
+            int cnt = hi >= lo ? hi - lo + 1 : 0;
+            if (cnt == 0) lo = 0;
+            cnt = (cnt + 3) & ~3;                       // the kernel works in fours: the extra groups carry zero weights and stay
+            if (lo + cnt > 52) lo = 52 - cnt;           // inside the 52 groups (208 rows) of the spectrum block
+            f->mel_lo[mt] = lo; f->mel_cnt[mt] = cnt; f->mel_off[mt] = groups_total;
+            host.resize(host.size() + (size_t)cnt * 64, 0.f);
+            for (int e = 0; e < cnt; ++e)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 4, m = 16 * mt + (lane & 15), b = 4 * (lo + e) + g;
+                    if (m < cfg->n_mel && b <= 200) host[f->fft_mel_off + ((size_t)(groups_total + e) * 64) + lane] = f->basis[(size_t)m * NF + b];
+                }
+            groups_total += cnt;
+        }
         const char* dense = getenv("KWS_FRONTEND_DENSE");      // A/B switch: the dense-DFT kernel also handles 400
         f->use_fft = !(dense && dense[0] == '1');
     }
@@ -1110,7 +1120,7 @@ static int frontend_run_impl(kws_frontend_handle h, const float* carry, int n_ca
     if (B == 0 || T == 0) return KWS_OK;
     if (!chunk || !mel || (n_carry > 0 && !carry)) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
     if ((long long)B * T > (1LL << 36)) return fail(KWS_ERR_UNSUPPORTED, "B*T=%lld frames exceed the grid limit", (long long)B * T);
-    kws::FrontendParams p;
+    kws::FrontendParams p = {};
     p.pcm = chunk; p.carry = n_carry > 0 ? carry : chunk; p.mel = mel;
     p.dft = h->d_tables + h->dft_off; p.melw = h->d_tables + h->melw_off;
     p.n_samples = n_samples; p.n_carry = n_carry; p.T = T; p.fft = h->cfg.fft_size; p.hop = h->cfg.hop_size; p.n_mel = h->cfg.n_mel;
@@ -1118,6 +1128,7 @@ static int frontend_run_impl(kws_frontend_handle h, const float* carry, int n_ca
     hipError_t e;
     if (h->use_fft && (long long)B * T < (1LL << 31)) {
         p.dft = h->d_tables + h->fft_tw_off; p.melw = h->d_tables + h->fft_mel_off;
+        for (int m = 0; m < 4; ++m) { p.mel_lo[m] = h->mel_lo[m]; p.mel_cnt[m] = h->mel_cnt[m]; p.mel_off[m] = h->mel_off[m]; }
         e = kws::launch_mel_fft400(p, B, static_cast<hipStream_t>(stream));
     } else {
         e = kws::launch_mel_frontend(p, B, static_cast<hipStream_t>(stream));

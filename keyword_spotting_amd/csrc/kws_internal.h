@@ -154,9 +154,13 @@ struct FrontendParams {
     const float* dft;    // [nf_tiles x (cos|sin) x parity][kc4][64][4]  A fragments: bins 0..fft/4 over the folded samples of one parity
     const float* melw;   // [mel_tiles][nf_tiles][direct|mirror][4][64]  A fragments of the mel basis, xl k map over k = 0..fft/4
     int n_samples, T, fft, hop, n_mel, nf_tiles, mel_tiles, kc4, B, n_carry;   // n_samples = n_carry + new samples
+#ifdef KWS_FE_TIMING
+    long long* timing;
+#endif
+    int mel_lo[4], mel_cnt[4], mel_off[4];   // fft_frontend.hip: per mel tile, first 4-bin group, number of groups (multiple of 4), offset of its fragments in melw (in groups)
 };
 hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st);
-// fft 400 only (fft_frontend.hip): p.dft = twiddles [12][16] (cos, sin), p.melw = basis fragments [4][16][mel_tiles][64]
+// fft 400 only (fft_frontend.hip): p.dft = twiddles [12][16] (cos, sin), p.melw = basis fragments [tile][group of its run][64]
 hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st);
 hipError_t launch_carry_tail(const float* carry, int n_carry, const float* chunk, int n_chunk, float* next, int n_next, int B,
                              hipStream_t st);
