@@ -27,10 +27,43 @@ PEAK_FP32_TFLOPS = 157.3                                                      # 
 PEAK_HBM_GBS = 8000.0
 
 
+def rocprof_kernel_avg_ms(pattern, tag=None):
+    """Average duration (ms) of the first kernel whose name contains `pattern` in the latest committed
+    profiles/r<round>[_<tag>]_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command), and the file."""
+    import csv
+    import glob
+    import re
+    rx = re.compile(r"^r(\d+)_kernel_stats\.csv$" if tag is None else r"^r(\d+)_%s_kernel_stats\.csv$" % re.escape(tag))
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.csv")) if rx.match(os.path.basename(f))]
+    if not files:
+        return None, None
+    latest = max(files, key=lambda f: int(rx.match(os.path.basename(f)).group(1)))
+    for row in csv.DictReader(open(latest)):
+        if pattern in row.get("Name", ""):
+            return float(row["AverageNs"]) * 1e-6, os.path.relpath(latest, ROOT)
+    return None, os.path.relpath(latest, ROOT)
+
+
+def pmc_bytes(pattern, tag):
+    """HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of a kernel in profiles/r<round>_<tag>_pmc.json."""
+    import glob
+    import re
+    rx = re.compile(r"^r(\d+)_%s_pmc\.json$" % re.escape(tag))
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")) if rx.match(os.path.basename(f))]
+    if not files:
+        return None, None
+    latest = max(files, key=lambda f: int(rx.match(os.path.basename(f)).group(1)))
+    for k, c in json.load(open(latest)).items():
+        if pattern in k and "hbm_bytes_per_launch" in c:
+            return c["hbm_bytes_per_launch"], os.path.relpath(latest, ROOT)
+    return None, os.path.relpath(latest, ROOT)
+
+
 def secondary_lines(device):
     """Informational figures for the other BASELINE configs, measured after the timed region on rank 0 (never part of
-    `value`): the bf16 and int8 variants of the headline workload, the end-to-end PCM -> trigger streaming loop and
-    configs[4].  A few seconds in total."""
+    `value`): the bf16 and int8 variants of the headline workload, the end-to-end PCM -> trigger streaming loop (fp32 and
+    bf16 stacks, with a roofline per kernel of the loop) and configs[4].  Every entry carries its own roofline figures so
+    that the driver-run line alone holds them.  A few seconds in total."""
     import torch
     from keyword_spotting_amd import get_config, weights
     from keyword_spotting_amd.detector import StreamManager
@@ -47,38 +80,101 @@ def secondary_lines(device):
         torch.cuda.synchronize(device)
         return (time.perf_counter() - t0) / n
 
+    def events(fn, n):
+        """ms per call by HIP events on the stream the kernels are launched on (torch's current stream)."""
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b) / n
+
     out = {}
     B, T = 4096, 300
+    valu_pk_i16_peak = 256 * 64 * 2.4e9 * (8.0 / 3.0) / 1e12          # exact maddubs emulation: 8 int ops per 3 lane-instructions
     for prec, steps in (("bf16", 5), ("int8", 3)):
         cfg = get_config(precision=prec)
         m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
         mel = (torch.randn(B, T, cfg.n_mel, device=device).abs() * 2).contiguous()
         st, pw = m.zero_state(B), m.fresh_prev_word(B)
+        m.set_profiling(True)
         dt = timed(lambda: m.forward(mel, st, prev_word=pw, state_out=st), steps)
-        out["configs[2] %s, %d streams x %d frames" % (prec, B, T)] = {"mel_frames_per_s": B * T / dt, "ms_per_step": dt * 1e3}
+        kt = m.kernel_times()
+        entry = {"mel_frames_per_s": B * T / dt, "ms_per_step": dt * 1e3}
+        if prec == "bf16":
+            ms = kt[0][0] / max(kt[0][1], 1)
+            tf = FLOP_PER_FRAME["total"] * B * T / (ms * 1e-3) / 1e12
+            entry["roofline"] = {"bound": "mfma", "kernel": "gru_stack_bf16 (both layers fused)", "kernel_ms": ms, "achieved": tf,
+                                 "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                                 "hbm_algorithmic_GBps": BYTES_PER_FRAME * B * T / (ms * 1e-3) / 1e9}
+        else:
+            ms = kt[1][0] / max(kt[1][1], 1)
+            tops = FLOP_PER_FRAME["layer"][1] * B * T / (ms * 1e-3) / 1e12
+            entry["roofline"] = {"bound": "valu-pk-i16", "kernel": "gru_layer_octbit layer 1 + projection", "kernel_ms": ms, "achieved": tops,
+                                 "peak": valu_pk_i16_peak, "unit": "TOP/s", "frac": tops / valu_pk_i16_peak,
+                                 "per_layer_ms": [k[0] / max(k[1], 1) for k in kt]}
+        out["configs[2] %s, %d streams x %d frames" % (prec, B, T)] = entry
         m.close()
-    cfg = get_config()
-    m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
-    fe, mgr = MelFrontend(cfg), StreamManager(m, B)
+    # the loop the reference ships: PCM chunks of 225 ms in, trigger decisions out (kws_stream_feed)
     pcm = [(torch.randn(B, 3600, device=device) * 0.1).contiguous() for _ in range(4)]
-    k = [0]
-    def chunk():
-        mgr.feed_pcm(pcm[k[0] % 4], fe)
-        k[0] += 1
-    for _ in range(3):
-        chunk()
-    dt = timed(chunk, 20)
-    out["detector.py loop, PCM in -> trigger out, fp32, %d streams x 225 ms chunks (VAD, front-end, GRU, window)" % B] = {
-        "realtime_streams": B * 0.225 / dt, "ms_per_chunk": dt * 1e3}
-    m.close()
+    fe_ms = None
+    for prec in ("fp32", "bf16"):
+        cfg = get_config(precision=prec)
+        m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+        fe, mgr = MelFrontend(cfg), StreamManager(m, B)
+        k = [0]
+        def chunk():
+            mgr.feed_pcm(pcm[k[0] % 4], fe)
+            k[0] += 1
+        for _ in range(3):
+            chunk()
+        m.set_profiling(True)
+        m.kernel_times()
+        dt = timed(chunk, 20)
+        kt = m.kernel_times()
+        m.set_profiling(False)
+        frames = B * 22.5                                   # 3600-sample hops: 22 and 23 frames alternate
+        entry = {"realtime_streams": B * 0.225 / dt, "ms_per_chunk": dt * 1e3}
+        if prec == "fp32":
+            per = [k_[0] / max(k_[1], 1) for k_ in kt]
+            entry["gru_kernels"] = [{"kernel": "gru_layer_resident layer %d" % l, "kernel_ms": per[l],
+                                     "tflops": FLOP_PER_FRAME["layer"][l] * frames / (per[l] * 1e-3) / 1e12,
+                                     "frac": FLOP_PER_FRAME["layer"][l] * frames / (per[l] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+                                    for l in range(len(per))]
+            # the front-end kernel alone on one chunk with its carried samples (22 frames per stream): HBM-bound,
+            # algorithmic bytes = PCM in (3840 samples) + mel out
+            carry = torch.zeros(B, 240, device=device)
+            fe_ms = events(lambda: fe.forward_carry(carry, pcm[0], 240), 20)
+            alg = B * (3840 * 4 + 22 * cfg.n_mel * 4)
+            traffic, src = pmc_bytes("mel_fft400_kernel", "fe")
+            rp_ms, rp_src = rocprof_kernel_avg_ms("mel_fft400_kernel", "fe")
+            entry["frontend"] = {"kernel": "mel_fft400_kernel (16x25 real FFT + mel MFMA) + carry_tail", "kernel_ms": fe_ms,
+                                 "mel_frames_per_s": B * 22 / (fe_ms * 1e-3),
+                                 "roofline": {"bound": "hbm", "achieved": alg / (fe_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                              "frac": alg / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg,
+                                              "traffic": traffic, "traffic_source": src,
+                                              "kernel_ms_rocprof": rp_ms, "rocprof_source": rp_src}}
+        else:
+            ms = kt[0][0] / max(kt[0][1], 1)
+            entry["gru_kernels"] = [{"kernel": "gru_stack_bf16", "kernel_ms": ms,
+                                     "tflops": FLOP_PER_FRAME["total"] * frames / (ms * 1e-3) / 1e12,
+                                     "frac": FLOP_PER_FRAME["total"] * frames / (ms * 1e-3) / 1e12 / 2500.0}]
+        out["detector.py loop, PCM in -> trigger out, %s, %d streams x 225 ms chunks (VAD, front-end, GRU, window)" % (prec, B)] = entry
+        mgr.close()
+        m.close()
     cfg = get_config(n_mel=60, hidden_size=256, num_layers=4)
     m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
     mel = (torch.randn(1024, T, 60, device=device).abs() * 2).contiguous()
     st = m.zero_state(1024)
     dt = timed(lambda: m.forward(mel, st, state_out=st), 5)
     macs = sum(((60 if l == 0 else 256) + 256) * 3 * 256 for l in range(4)) + 256 * 6
+    tf = 2 * macs * 1024 * T / dt / 1e12
     out["configs[4] 4xGRU h=256 n_mel=60, 1024 streams x %d frames, fp32 (layer-pipelined launch)" % T] = {
-        "mel_frames_per_s": 1024 * T / dt, "ms_per_step": dt * 1e3, "tflops": 2 * macs * 1024 * T / dt / 1e12}
+        "mel_frames_per_s": 1024 * T / dt, "ms_per_step": dt * 1e3, "tflops": tf, "frac": tf / PEAK_FP32_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": "gru_stack_generic_pipelined<4>", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS}}
     m.close()
     return out
 
@@ -302,6 +398,7 @@ def main(argv=None, model_factory=None):
         # the dominant kernel's own share of those boundary bytes; the fp32 inter-layer seam (512 B/frame written by
         # layer 0 and read back by layer 1) is INTERNAL traffic, not algorithmic work -- it is what `traffic` exceeds by
         dom_alg = ((160 if dom == 0 else 49) if args.precision != "bf16" else BYTES_PER_FRAME) * B * T
+        rp_ms, rp_src = (rocprof_kernel_avg_ms(dom_name) if B == 4096 and T == 300 and pmc else (None, None))
         line = {
             "metric": "mel-frames/s (real-time 10 ms-hop audio streams sustained = value/100)",
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
@@ -316,7 +413,11 @@ def main(argv=None, model_factory=None):
                        "kernel": getattr(model, "kernel", "stub")},
             "realtime_streams": value / 100.0,
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / peak,
+                         # the same fraction from the committed rocprofv3 kernel-trace average of this command (tracer attached)
+                         "frac_rocprof": (dom_flops * B * T / (rp_ms * 1e-3) / 1e12 / peak) if rp_ms else None,
+                         "kernel_ms_rocprof": rp_ms, "rocprof_source": rp_src,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_alg,
                          "seam_bytes_per_launch": 0 if args.precision == "bf16" else 512 * B * T,
                          "path_algorithmic_bytes_per_step": path_bytes,

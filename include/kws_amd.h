@@ -92,23 +92,28 @@ size_t kws_weights_nbytes(const kws_config* cfg);
 /* Stages the weights on the current HIP device (re-tiled into MFMA fragment order) and returns a
  * handle.  `weights_blob` is HOST memory of kws_weights_nbytes(cfg) bytes. */
 int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, kws_handle* out);
+/* Releases the handle and always returns KWS_OK (the handle is gone afterwards, whatever it reports: never retry).  An
+ * error a finished asynchronous step had raised and nobody collected is left in kws_last_error(); call kws_poll_error
+ * first to get it as a status.  Stream handles created on it (kws_stream_create) fail cleanly afterwards. */
 int kws_destroy(kws_handle h);
 
 /* Kernel family used by kws_step (fp32): AUTO picks the register-resident kernels when the shape allows
  * (hidden == 128 and n_mel in {32, 40, 48, 60, 64}), else the generic ones (hidden 64/128/256, any n_mel).
  * RESIDENT on an unsupported shape -> KWS_ERR_UNSUPPORTED.  Ignored by the bf16 stack. */
 int kws_set_kernel(kws_handle h, int kind);
-/* Pre-sizes the handle's scratch for calls of up to B streams x T frames: afterwards kws_step on any shape whose
- * scratch fits never allocates or synchronises, whichever launch layout it picks (sequential layers, layers overlapped
- * on HIP streams, layer-pipelined launch).  The scratch only grows. */
+/* Pre-sizes the handle's scratch for calls of B streams x up to T frames: afterwards kws_step with this B and T' <= T
+ * never allocates or synchronises, whichever launch layout it picks for that shape (sequential layers, layers overlapped
+ * on HIP streams, layer-pipelined launch).  A later call with a DIFFERENT B may select a layout this call did not size
+ * (e.g. a smaller batch that becomes eligible for the layer-pipelined launch) and then grows the scratch once, which
+ * synchronises: reserve every batch size you will use.  The scratch only grows. */
 int kws_reserve(kws_handle h, int B, int T);
 /* bytes_reserved: device scratch currently held for inter-layer seams; allocations: how many times it (or another
  * batch-sized side buffer) was (re)allocated -- each of those synchronised the device.  Either pointer may be NULL. */
 int kws_scratch_stats(kws_handle h, size_t* bytes_reserved, int32_t* allocations);
 /* KWS_OK, or the error a finished asynchronous step of this handle raised on the device (today: a layer-pipelined
  * launch whose wait for the layer below timed out -- the results of that step are invalid).  Does not synchronise: to
- * validate a given step, synchronise its stream first.  The same condition is also reported by the next kws_step,
- * by kws_kernel_times and by kws_destroy, whichever comes first; reporting clears it. */
+ * validate a given step, synchronise its stream first.  The same condition is also reported by the next kws_step and
+ * by kws_kernel_times, whichever comes first; reporting clears it.  (kws_destroy only leaves it in kws_last_error().) */
 int kws_poll_error(kws_handle h);
 
 /* Advances B independent streams by T frames (one 10 ms hop each).
@@ -200,10 +205,14 @@ int kws_window_step(kws_window_handle h, const float* softmax /*[B,T,C]*/, int T
  *   prob_queue.add(softmax); ctc_decode2 over the window; ctc_predict(label)                            (:195-201)
  *   on a hit: window cleared, state reset requested for the next chunk                                  (:202-208)
  * i.e. kws_vad -> kws_frontend_run_carry -> kws_step -> kws_window_step with the mask logic between them fused into
- * the first kernel and no host work per stream.  The handle BORROWS the model, front-end and window handles (they must
- * outlive it) and the caller-owned device buffers `state` [L,B,H] (zero it to start) and `restart` [B] u8 (zero it);
- * it owns the sample carry, the mel / softmax staging and the masks.  Fewer than fft_size samples in total so far:
- * everything is carried, hit = 0 (as the front-end yields no frame).  `label`: digits '1'..'9'. */
+ * the first kernel and no host work per stream.  The handle BORROWS the model, front-end and window handles (they
+ * should outlive it; a feed after one of them was destroyed fails with KWS_ERR_INVALID_ARGUMENT) and the caller-owned
+ * device buffers `state` [L,B,H] (zero it to start) and `restart` [B] u8 (zero it); it owns the sample carry, the
+ * mel / softmax staging and the masks.  An empty chunk (n == 0) is skipped as detector.py:164-166 does.  Fewer than
+ * fft_size samples in total so far: the reference still runs its whole iteration on such a chunk, and so does this --
+ * the VAD decision clears state and window, every sample is carried, the model runs over zero frames (state handed
+ * back, or zeroed where the VAD said silence) and the empty softmax takes a slot of the window before the windowed
+ * decode.  `label`: digits '1'..'9'. */
 typedef struct kws_stream* kws_stream_handle;
 int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window_handle window, int B, int max_chunk_samples,
                       float vad_thres, const char* label, float* state, uint8_t* restart, kws_stream_handle* out);

@@ -96,19 +96,21 @@ __global__ void ctc_predict_kernel(const int32_t* __restrict__ words, const int3
     hit[b] = found;
 }
 
-// one workgroup per stream: sum |x| in fp32 (wave shuffle + LDS), compare with the threshold
-// sum_n |x[n]| of one row by a 256-thread block (utils/basic_vad.py:17-18).  ONE summation order for every caller --
-// kws_vad and the stream manager's gate kernel must take identical decisions: 16-byte loads (4 samples per lane and
-// trip, 8 for int16) when the row allows it, per-thread partial sums, wave shuffles, then the four wave totals.
+// sum_n |x[n]| of one row by a 256-thread block in fp32 (utils/basic_vad.py:17-18).  ONE summation order for every caller
+// and every buffer -- kws_vad and the stream manager's gate kernel must take identical decisions, whatever the alignment of
+// the row: thread t owns the groups of four samples t, t + 256, ...; a group is summed (|a|+|b|)+(|c|+|d|) and added to the
+// thread's partial sum, then wave shuffles, then the four wave totals.  Aligned rows fetch a group with one 8/16-byte load,
+// unaligned rows and the tail group (N % 4 samples, padded with +0) sample by sample: the arithmetic is the same.
 template <typename SampleT>
 __device__ __forceinline__ float block_abs_sum(const SampleT* __restrict__ x, int N, float* __restrict__ widened) {
     constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;      // detector.py:40-43: int16 -> [-1, 1)
     float acc = 0.f;
-    const bool vec = (N & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(SampleT) - 1)) == 0 &&
-                     (!widened || (reinterpret_cast<uintptr_t>(widened) & 15) == 0);
-    if (vec) {
-        for (int i = threadIdx.x; i < N / 4; i += 256) {
-            float v[4];
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(SampleT) - 1)) == 0;
+    const bool wvec = widened && (reinterpret_cast<uintptr_t>(widened) & 15) == 0;
+    const int full = N / 4;
+    for (int i = threadIdx.x; i < (N + 3) / 4; i += 256) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i < full && vec) {
             if constexpr (sizeof(SampleT) == 2) {
                 const short4 q = reinterpret_cast<const short4*>(x)[i];
                 v[0] = (float)q.x * kScale; v[1] = (float)q.y * kScale; v[2] = (float)q.z * kScale; v[3] = (float)q.w * kScale;
@@ -116,15 +118,21 @@ __device__ __forceinline__ float block_abs_sum(const SampleT* __restrict__ x, in
                 const float4 q = reinterpret_cast<const float4*>(x)[i];
                 v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
             }
-            if (widened) reinterpret_cast<float4*>(widened)[i] = make_float4(v[0], v[1], v[2], v[3]);
-            acc += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * i + e < N) v[e] = (float)x[4 * i + e] * kScale;
         }
-    } else {
-        for (int i = threadIdx.x; i < N; i += 256) {
-            const float v = (float)x[i] * kScale;
-            if (widened) widened[i] = v;
-            acc += fabsf(v);
+        if (widened) {
+            if (i < full && wvec) {
+                reinterpret_cast<float4*>(widened)[i] = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * i + e < N) widened[4 * i + e] = v[e];
+            }
         }
+        acc += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     __shared__ float part[4];
@@ -159,6 +167,19 @@ __global__ void __launch_bounds__(256) vad_gate_kernel(const SampleT* __restrict
         silent[b] = quiet;
         reset[b] = (quiet || (restart && restart[b])) ? 1 : 0;
     }
+}
+
+__global__ void state_passthrough_kernel(const float* __restrict__ state_in, float* __restrict__ state_out, const uint8_t* __restrict__ reset,
+                                         int L, int B, int H) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)L * B * H) return;
+    const int b = (int)((i / H) % B);
+    state_out[i] = reset[b] ? 0.f : state_in[i];
+}
+hipError_t launch_state_passthrough(const float* state_in, float* state_out, const uint8_t* reset, int L, int B, int H, hipStream_t st) {
+    const size_t n = (size_t)L * B * H;
+    hipLaunchKernelGGL(state_passthrough_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, state_in, state_out, reset, L, B, H);
+    return hipGetLastError();
 }
 
 hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,

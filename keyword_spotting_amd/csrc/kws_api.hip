@@ -5,8 +5,10 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kws_internal.h"
@@ -14,6 +16,27 @@
 namespace {
 
 thread_local std::string g_last_error;
+
+// Live handles (model / front-end / window): a stream handle borrows all three, and its owner may destroy one of them
+// first.  kws_stream_feed checks its borrowed pointers here -- pointer AND the serial it saw at kws_stream_create, so a new
+// handle that reuses a freed address does not pass -- and fails with KWS_ERR_INVALID_ARGUMENT instead of touching freed
+// memory.
+std::mutex g_live_mutex;
+std::unordered_map<const void*, unsigned long long> g_live;
+unsigned long long g_live_serial = 0;
+unsigned long long live_register(const void* h) {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    return g_live[h] = ++g_live_serial;
+}
+void live_unregister(const void* h) {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    g_live.erase(h);
+}
+unsigned long long live_serial(const void* h) {      // 0: not a live handle
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    const auto it = g_live.find(h);
+    return it == g_live.end() ? 0ull : it->second;
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -104,6 +127,7 @@ struct kws_stream {
     kws_model* model = nullptr;
     kws_frontend* fe = nullptr;
     kws_window* win = nullptr;
+    unsigned long long model_serial = 0, fe_serial = 0, win_serial = 0;   // live_serial() of the three at kws_stream_create
     int B = 0, max_chunk = 0, tmax = 0, n_carry = 0, cur = 0;
     float vad_thres = 0.f;
     char label[17] = {0};
@@ -436,12 +460,14 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
     if (e != hipSuccess) { hipFree(m->d_weights); delete m; return hip_fail(e, "hipDeviceSynchronize(weights)"); }
     m->ms_sum.assign(cfg->num_layers, 0.f);
     m->launches.assign(cfg->num_layers, 0);
+    live_register(m);
     *out = m;
     return KWS_OK;
 }
 
 int kws_destroy(kws_handle h) {
     if (!h) return KWS_OK;
+    live_unregister(h);
     hipDeviceSynchronize();
     for (auto& pd : h->pending) { hipEventDestroy(pd.a); hipEventDestroy(pd.b); }
     for (auto ev : h->event_pool) hipEventDestroy(ev);
@@ -459,8 +485,11 @@ int kws_destroy(kws_handle h) {
     if (h->oct_range) hipFree(h->oct_range);
     if (h->oct_prev) hipFree(h->oct_prev);
     delete h;
+    // The handle is gone whatever happened before: always KWS_OK (a caller that read a failure as "still alive" would free it
+    // twice).  A pipelined step that timed out and was never followed by another call is left in kws_last_error().
     if (pipe_failed)
-        return fail(KWS_ERR_HIP, "the last layer-pipelined step of this handle timed out waiting for the layer below; its results were invalid");
+        fail(KWS_OK, "kws_destroy: the last layer-pipelined step of this handle had timed out waiting for the layer below; its results "
+                     "were invalid (kws_poll_error before kws_destroy reports this as a status)");
     return KWS_OK;
 }
 
@@ -779,11 +808,26 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         h->ovl_tail_valid = false;
     }
     if (T == 0) {
-        if (state_out != state_in)
+        // dynamic_rnn over zero frames hands the initial state back -- and clean_state() (detector.py:313-316) has already
+        // zeroed it for the streams the mask names
+        if (reset_mask) {
+            hipError_t e = kws::launch_state_passthrough(state_in, state_out, reset_mask, L, B, H, st);
+            if (e != hipSuccess) return hip_fail(e, "launch state_passthrough");
+        } else if (state_out != state_in) {
             KWS_HIP(hipMemcpyAsync(state_out, state_in, (size_t)L * B * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
         return KWS_OK;
     }
     if (!mel) return fail(KWS_ERR_INVALID_ARGUMENT, "mel is null");
+    if (c.precision != KWS_BF16) {
+        // the streaming kernels address a group's seam (T x H/16 KiB) through buffer instructions with 32-bit offsets
+        bool streaming = false;
+        for (const auto& Ld : h->layers)
+            streaming |= !(h->kernel_kind == KWS_KERNEL_RESIDENT || (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok));
+        if (streaming && (long long)T * (H / 16) >= (1LL << 21))
+            return fail(KWS_ERR_UNSUPPORTED, "T=%d frames of hidden=%d exceed the 2 GiB a stream group's seam may span: split the call "
+                        "(state carried across calls gives identical results)", T, H);
+    }
     if (c.precision == KWS_BF16) {
         if ((reinterpret_cast<uintptr_t>(mel) & 15) != 0) return fail(KWS_ERR_INVALID_ARGUMENT, "mel must be 16-byte aligned");
         kws::GruBf16Params bp;
@@ -955,12 +999,14 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres,
     if (e == hipSuccess) e = kws::launch_window_reset(B, wnd->head, wnd->count, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { kws_window_destroy(wnd); return hip_fail(e, "kws_window_create"); }
+    live_register(wnd);
     *out = wnd;
     return KWS_OK;
 }
 
 int kws_window_destroy(kws_window_handle h) {
     if (!h) return KWS_OK;
+    live_unregister(h);
     hipDeviceSynchronize();
     if (h->words) hipFree(h->words);
     if (h->lens) hipFree(h->lens);
@@ -1095,12 +1141,14 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
     e = hipMemcpy(f->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { hipFree(f->d_tables); delete f; return hip_fail(e, "hipMemcpy(frontend tables)"); }
+    live_register(f);
     *out = f;
     return KWS_OK;
 }
 
 int kws_frontend_destroy(kws_frontend_handle h) {
     if (!h) return KWS_OK;
+    live_unregister(h);
     hipDeviceSynchronize();
     if (h->d_tables) hipFree(h->d_tables);
     delete h;
@@ -1170,6 +1218,8 @@ int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window
     if (!out) return fail(KWS_ERR_INVALID_ARGUMENT, "out handle pointer is null");
     *out = nullptr;
     if (!model || !frontend || !window || !state || !restart || !label) return fail(KWS_ERR_INVALID_ARGUMENT, "null argument");
+    const unsigned long long ms = live_serial(model), fs = live_serial(frontend), ws = live_serial(window);
+    if (!ms || !fs || !ws) return fail(KWS_ERR_INVALID_ARGUMENT, "model, front-end or window handle is not alive (destroyed, or not a handle)");
     if (B < 1 || max_chunk_samples < 1) return fail(KWS_ERR_INVALID_ARGUMENT, "bad stream shape B=%d max_chunk_samples=%d", B, max_chunk_samples);
     const int n = (int)strlen(label);
     if (n > 16) return fail(KWS_ERR_INVALID_ARGUMENT, "label longer than 16 digits");
@@ -1187,6 +1237,7 @@ int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window
                     tmax, window->tmax);
     kws_stream* s = new (std::nothrow) kws_stream();
     if (!s) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->model_serial = ms; s->fe_serial = fs; s->win_serial = ws;
     s->model = model; s->fe = frontend; s->win = window; s->B = B; s->max_chunk = max_chunk_samples; s->tmax = tmax;
     s->vad_thres = vad_thres; s->state = state; s->restart = restart;
     memcpy(s->label, label, n);
@@ -1225,6 +1276,8 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
     if (n < 0 || n > h->max_chunk) return fail(KWS_ERR_INVALID_ARGUMENT, "chunk of %d samples outside [0,%d]", n, h->max_chunk);
     if (!hit || (!pcm && n > 0)) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (live_serial(h->model) != h->model_serial || live_serial(h->fe) != h->fe_serial || live_serial(h->win) != h->win_serial)
+        return fail(KWS_ERR_INVALID_ARGUMENT, "the model, front-end or window this stream was created on has been destroyed");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const kws_frontend_config& fc = h->fe->cfg;
     const int fft = fc.fft_size, hop = fc.hop_size, B = h->B;
@@ -1232,17 +1285,23 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
     const float* chunk = pcm_int16 ? h->pcm_f32 : static_cast<const float*>(pcm);
     const float* carry = h->carry[h->cur];
     float* next = h->carry[h->cur ^ 1];
-    if (total < fft) {
-        // not a full frame yet: everything is carried, no model run, no decision (the int16 samples still have to be widened)
-        if (pcm_int16 && n > 0) {
-            hipError_t e = kws::launch_vad_gate(pcm, 1, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset, st);
-            if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
-        }
-        if (total > 0) {
-            hipError_t e = kws::launch_carry_tail(h->n_carry ? carry : chunk, h->n_carry, n ? chunk : carry, n, next, total, B, st);
-            if (e != hipSuccess) return hip_fail(e, "launch carry_tail");
-        }
+    if (n == 0) {            // detector.py:164-166: an empty read is skipped before anything else happens
         KWS_HIP(hipMemsetAsync(hit, 0, (size_t)B * sizeof(int32_t), st));
+        return KWS_OK;
+    }
+    if (total < fft) {
+        // Not a full frame yet.  The reference still runs the whole iteration on such a chunk (detector.py:168-209): vad ->
+        // clean_state() + prob_queue.clear() when silent, the samples are carried (:179-183 keeps all of them), sess.run over
+        // zero frames returns the state unchanged and an empty softmax, which takes a slot of the window (:195) before the
+        // windowed decode (:197-201).
+        hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset, st);
+        if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
+        e = kws::launch_carry_tail(h->n_carry ? carry : chunk, h->n_carry, chunk, n, next, total, B, st);
+        if (e != hipSuccess) return hip_fail(e, "launch carry_tail");
+        int rc = kws_step(h->model, nullptr, h->state, nullptr, nullptr, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, 0, st);
+        if (rc != KWS_OK) return rc;
+        rc = kws_window_step(h->win, nullptr, 0, h->silent, h->label, hit, h->restart, st);
+        if (rc != KWS_OK) return rc;
         h->n_carry = total; h->cur ^= 1;
         return KWS_OK;
     }

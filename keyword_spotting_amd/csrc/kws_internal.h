@@ -181,6 +181,8 @@ hipError_t launch_ctc_predict(const int32_t* words, const int32_t* counts, int B
 hipError_t launch_vad(const float* pcm, int B, int N, float thres, uint8_t* speech, float* abs_sum,
                       hipStream_t st);
 
+// state_out = reset[b] ? 0 : state_in for [L,B,H] (a kws_step over zero frames; in-place allowed)
+hipError_t launch_state_passthrough(const float* state_in, float* state_out, const uint8_t* reset, int L, int B, int H, hipStream_t st);
 hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,
                            uint8_t* silent, uint8_t* reset, hipStream_t st);
 

@@ -93,6 +93,7 @@ class HotwordDetector(object):
             for b in np.nonzero(~np.asarray(speech, bool))[0]:       # :171-177
                 self.clean_state(int(b))
                 self.prob_queue[int(b)].clear()
+        # (zero frames: dynamic_rnn hands the state back, clean_state() has zeroed it where the mask says so)
         r = self.model.forward(mel, self.state, reset_mask=self.reset_next, want_logits=False, want_softmax=True,
                                state_out=self.state)
         self.reset_next.zero_()
@@ -129,12 +130,17 @@ class HotwordDetector(object):
         chunk = buf_to_float(chunk.to(self.model.device))             # int16 PCM -> [-1, 1) as RingBuffer.get does (:74-79)
         if not hasattr(self, "res"):
             self.res = chunk[:, :0]                                   # :125
+        if chunk.shape[1] == 0:                                       # :164-166: an empty read is skipped
+            return []
         data = torch.cat([self.res, chunk], 1)                        # :179
         fft, hop = self.config.fft_size, self.config.hop_size
         n = int(data.shape[1])
-        if n < fft:                                                   # not a full frame yet: carry everything
+        if n < fft:
+            # not a full frame yet: the reference still runs the whole iteration -- vad / clean_state / queue.clear (:168-177),
+            # every sample carried (:181-183 keeps them all), sess.run over zero frames, an empty softmax into the queue (:195)
             self.res = data
-            return []
+            mel = torch.zeros(self.batch, 0, self.config.n_mel, device=self.model.device)
+            return self.feed(mel, pcm_chunk=chunk)
         keep = (n - fft) % hop + (fft - hop)                          # :181-182
         self.res = data[:, n - keep:].contiguous()                    # :183
         mel = frontend.forward(data.contiguous())
@@ -180,12 +186,12 @@ class StreamManager(object):
         self.restart = torch.zeros(self.batch, dtype=torch.uint8, device=dev)     # reset requested by a trigger
         self.hit = torch.zeros(self.batch, dtype=torch.int32, device=dev)
         self.max_frames = int(max_frames)
-        self._stream, self._stream_frontend = None, None
+        self._stream, self._stream_frontend, self._stream_fe_handle = None, None, None
 
     def _close_stream(self):
         if getattr(self, "_stream", None) is not None and self._stream.value:
             self._lib.kws_stream_destroy(self._stream)
-        self._stream, self._stream_frontend = None, None
+        self._stream, self._stream_frontend, self._stream_fe_handle = None, None, None
 
     def close(self):
         self._close_stream()
@@ -240,7 +246,9 @@ class StreamManager(object):
             raise _lib.InvalidArgumentError(-1, "expected float or int16 PCM, got %s" % chunk.dtype)
         chunk = chunk.to(self.model.device).contiguous()
         dev = self.model.device
-        if self._stream is None or self._stream_frontend is not frontend:
+        if not self.model._handle.value or not frontend._handle.value:
+            raise _lib.InvalidArgumentError(-1, "the model or the front-end has been closed")
+        if self._stream is None or self._stream_frontend is not frontend or self._stream_fe_handle != frontend._handle.value:
             self._close_stream()
             self._stream = ctypes.c_void_p()
             with torch.cuda.device(dev):
@@ -248,7 +256,7 @@ class StreamManager(object):
                                                        self.max_frames * int(self.config.hop_size), float(self.vad_thres),
                                                        self.label, _lib.ptr(self.state), _lib.ptr(self.restart),
                                                        ctypes.byref(self._stream)))
-            self._stream_frontend = frontend
+            self._stream_frontend, self._stream_fe_handle = frontend, frontend._handle.value
         with torch.cuda.device(dev):
             _lib.check(self._lib.kws_stream_feed(self._stream, _lib.ptr(chunk), int(chunk.shape[1]), is_i16, _lib.ptr(self.hit),
                                                  _lib.current_stream_ptr()))

@@ -88,6 +88,28 @@ def test_vad_from_pcm_drives_reset():
     assert np.abs(got - G.softmax(want)[0]).max() < 2e-5
 
 
+def test_vad_sum_does_not_depend_on_the_alignment_of_the_buffer():
+    """kws_vad and the stream manager's gate share one summation (block_abs_sum): the same samples give the same fp32
+    sum -- hence the same decision next to the threshold -- whether the rows allow 16-byte loads or not."""
+    from keyword_spotting_amd.basic_vad import vad
+    rng = np.random.default_rng(97)
+    for n in (3600, 3601, 250, 7):
+        flat = torch.from_numpy((rng.standard_normal(5 * n + 3) * 0.01).astype(np.float32)).cuda()
+        sums = []
+        for off in (0, 1, 2, 3):
+            x = flat[off:off + 5 * n].view(5, n)
+            if off:
+                x = x.clone() * 0 + flat[0:5 * n].view(5, n)       # same values ...
+                buf = torch.empty(5 * n + 4, device="cuda")
+                view = buf[off:off + 5 * n].view(5, n)             # ... at a row pointer that is off * 4 bytes past 16-byte alignment
+                view.copy_(x)
+                x = view
+            assert x.is_contiguous() and x.data_ptr() % 16 == (4 * off) % 16
+            sums.append(vad(x, 30, return_sum=True)[1].cpu().numpy())
+        for sm in sums[1:]:
+            np.testing.assert_array_equal(sm, sums[0])
+
+
 def test_test2_chunked_replay():
     from keyword_spotting_amd import get_config
     from keyword_spotting_amd.detector import ChunkFramer, HotwordDetector

@@ -278,3 +278,129 @@ def test_native_loop_random_chunk_lengths_equal_the_host_mirror(seed, as_int16):
         assert torch.equal(mgr.state, det.state), (c, n)
         fired += int(want.sum())
     assert fired > 0
+
+
+def _oracle_loop(w, chunks, label, window=15, vad_thres=30):
+    """detector.py:158-209 replayed with the oracle pieces only (numpy, fp64 model): per chunk -> (fired, the state the
+    model returned on that chunk, no frame near a decode threshold)."""
+    res = np.zeros(0, np.float32)
+    state = np.zeros((2, 1, 128), np.float64)
+    q = D.SimpleQueue(window)
+    out = []
+    for data in chunks:
+        if len(data) == 0:                                            # :164-166
+            out.append((False, state.copy(), True))
+            continue
+        if not D.vad(data, vad_thres):                                # :168-177
+            state[:] = 0
+            q.clear()
+        data = np.concatenate((res, data), 0)                         # :179
+        keep = (len(data) - 400) % 160 + 240                          # :181-182
+        res = data[-keep:]                                            # :183 (all of it when len(data) < 400)
+        margin_ok = True
+        if D.frames_in(len(data)) > 0:
+            lg, state = G.gru_forward(w, F.melspec(data[None], n_mels=40).astype(np.float32), state, dtype=np.float64)
+            sm = G.softmax(lg)[0]
+            p = np.sort(sm[:, 1:5], axis=1)
+            margin_ok = bool((np.abs(p[:, -1] - 0.4) > 1e-3).all() and (p[:, -1] - p[:, -2] > 1e-3).all())
+        else:
+            sm = np.zeros((0, 6))                                     # sess.run over zero frames
+        q.add(sm)                                                     # :195 -- an empty softmax still takes a slot
+        fired = bool(D.ctc_predict(D.ctc_decode2(np.concatenate(q.get_all(), 0), 6), label))   # :197-201
+        seen = state.copy()              # what sess.run returned: the device applies the trigger's clean_state() lazily,
+        if fired:                        # as a reset mask on the next run, so this is what its state buffer holds now
+            q.clear()                                                 # :203
+            state[:] = 0                                              # :208
+        out.append((fired, seen, margin_ok))
+    return out
+
+
+@pytest.mark.parametrize("as_int16", [False, True])
+def test_sub_frame_chunks_follow_the_reference_loop_against_the_oracle(as_int16):
+    """detector.py:168-177 runs on EVERY non-empty chunk, also one that is shorter than a frame: a silent 100-sample read
+    after speech zeroes the state and clears the window before its samples are carried; a speech one changes nothing but
+    still pushes an empty softmax into the 15-slot window.  Native loop and host mirror against an oracle-only replay."""
+    from keyword_spotting_amd.detector import HotwordDetector, StreamManager
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg, fe = _frontend()
+    w = G.init_weights(seed=3)
+    w["Wfc"] = (w["Wfc"] * 3).astype(np.float32)
+    rng = np.random.default_rng(271)
+    b = 3
+    probe = DeployModel(cfg, w)
+    sm = probe.forward(fe.forward(torch.from_numpy((rng.standard_normal((b, 8000)) * 0.2).astype(np.float32))),
+                       probe.zero_state(b), want_logits=False)["softmax"].cpu().numpy()
+    words = np.concatenate([D.ctc_decode2(sm[k], 6)[1::2] for k in range(b)])
+    label = str(int(np.bincount(words).argmax()))
+    # (length, which streams are silent): sub-frame silent after speech, sub-frame speech, empty read, silent full chunk
+    # (a 3600-sample chunk leaves 240..399 samples carried, so "shorter than a frame in total" means a few dozen samples)
+    plan = [(3600, []), (100, [0]), (3600, []), (50, []), (0, []), (3600, [1]), (60, [2]), (1, []), (3600, []), (30, [0, 1, 2]),
+            (3600, [])] + [(5, [])] * 17 + [(3600, [])]
+    carried, sub_frame = 0, []
+    for n, _ in plan:
+        total = carried + n
+        sub_frame.append(n > 0 and total < 400)
+        carried = total if total < 400 else (total - 400) % 160 + 240
+    assert sub_frame[1] and sub_frame[3] and sub_frame[7] and sum(sub_frame) >= 15
+    chunks = []
+    for n, quiet in plan:
+        x = rng.standard_normal((b, n)) * 0.2
+        x[quiet] *= 1e-4
+        if as_int16:
+            x = (x * 32768).clip(-32768, 32767).astype(np.int16)
+        else:
+            x = x.astype(np.float32)
+        chunks.append(x)
+    as_float = [c.astype(np.float32) / 32768.0 if as_int16 else c for c in chunks]
+    want = [_oracle_loop(w, [c[s] for c in as_float], label) for s in range(b)]
+    det = HotwordDetector(DeployModel(cfg, w), batch=b, label=label)
+    mgr = StreamManager(DeployModel(cfg, w), b, label=label)
+    ok = [True] * b
+    checked = fired = 0
+    for ci, piece in enumerate(chunks):
+        hits_d = np.zeros(b, np.int32)
+        hits_d[det.feed_pcm(torch.from_numpy(piece), fe)] = 1
+        hits_m = mgr.feed_pcm(torch.from_numpy(piece), fe).cpu().numpy()
+        np.testing.assert_array_equal(hits_m, hits_d, err_msg="chunk %d" % ci)
+        assert torch.equal(mgr.state, det.state), ci
+        st = mgr.state.cpu().numpy()
+        for s in range(b):
+            f, ostate, margin = want[s][ci]
+            ok[s] = ok[s] and margin
+            if not ok[s]:
+                continue                         # a frame within 1e-3 of a decode threshold: fp32 vs fp64 may decide differently
+            assert bool(hits_m[s]) == f, (ci, s)
+            assert np.abs(st[:, s] - ostate[:, 0]).max() < 1e-4, (ci, s)
+            checked += 1
+            fired += int(f)
+        if ci == 1:
+            assert not mgr.state[:, 0].any()      # the silent sub-frame read zeroed stream 0 at once, not one chunk later
+    assert checked > 2 * len(plan) and fired > 0
+
+
+def test_stream_handle_outliving_its_model_or_frontend_fails_cleanly():
+    """kws_stream borrows the model, front-end and window handles: feeding after one of them was destroyed is an
+    InvalidArgument error, not a use of freed memory."""
+    import ctypes
+    from keyword_spotting_amd import _lib
+    from keyword_spotting_amd.detector import StreamManager
+    from keyword_spotting_amd.frontend import MelFrontend
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg, fe = _frontend()
+    model = DeployModel(cfg, G.init_weights())
+    mgr = StreamManager(model, 2)
+    pcm = torch.zeros(2, 3600)
+    mgr.feed_pcm(pcm, fe)
+    stream = mgr._stream
+    lib = _lib.load()
+    hit = torch.zeros(2, dtype=torch.int32, device="cuda")
+    fe.close()
+    rc = lib.kws_stream_feed(stream, _lib.ptr(pcm.cuda()), 3600, 0, _lib.ptr(hit), None)
+    assert rc == _lib.KWS_ERR_INVALID_ARGUMENT and b"destroyed" in lib.kws_last_error()
+    with pytest.raises(_lib.InvalidArgumentError):
+        mgr.feed_pcm(pcm, fe)                                 # the Python wrapper notices the closed front-end itself
+    fe2 = MelFrontend(cfg)
+    mgr.feed_pcm(pcm, fe2)                                    # a new front-end: the stream is recreated
+    model.close()
+    with pytest.raises(_lib.InvalidArgumentError):
+        mgr.feed_pcm(pcm, fe2)

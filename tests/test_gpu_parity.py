@@ -92,6 +92,13 @@ def test_state_may_alias_and_empty_calls():
     assert torch.equal(r["state"], ref["state"]) and r["state"].data_ptr() == st2.data_ptr()
     e = m.forward(mel[:, :0].contiguous(), st)                   # T == 0: state passes through
     assert torch.equal(e["state"], st) and e["logits"].shape == (4, 0, 6)
+    # ... except for the streams clean_state() (detector.py:313-316) zeroed before this sess.run over zero frames
+    mask = torch.tensor([0, 1, 0, 1], dtype=torch.uint8)
+    e = m.forward(mel[:, :0].contiguous(), st, reset_mask=mask)
+    assert torch.equal(e["state"][:, 0::2], st[:, 0::2]) and not e["state"][:, 1::2].any()
+    st3 = st.clone()
+    m.forward(mel[:, :0].contiguous(), st3, reset_mask=mask, state_out=st3)          # in place
+    assert torch.equal(st3, e["state"])
     e = m.forward(mel[:0].contiguous(), st[:, :0].contiguous())  # B == 0
     assert e["logits"].shape == (0, 9, 6)
 
