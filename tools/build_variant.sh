@@ -15,14 +15,8 @@ while [ $# -gt 0 ]; do
   if [ "$1" == "--patch" ]; then P=$(realpath $2); (cd $W && patch -s -p1 < $P); shift 2; else FLAGS+=("$1"); shift; fi
 done
 C=$W/keyword_spotting_amd/csrc
-# per-file flags as in csrc/Makefile (FLAGS_<file>)
-OBJ=$W/obj; mkdir -p $OBJ
-for f in $C/*.hip; do
-  n=$(basename $f .hip); X=""
-  [ "$n" == "gru_bf16" ] && X="-mllvm -amdgpu-mfma-vgpr-form=1"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$C -Wno-unused-value -Wno-unused-result $X "${FLAGS[@]}" -c $f -o $OBJ/$n.o &
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/*.o -o $OUT/libkws_$NAME.so
+# the product's own Makefile (flags, per-file options) on the patched copy; include/ sits two levels above csrc there too
+mkdir -p $W/include && cp $ROOT/include/*.h $W/include/
+make -s -C $C -j8 OUT=$OUT/libkws_$NAME.so EXTRA="${FLAGS[*]}"
 rm -rf $W
 echo built $OUT/libkws_$NAME.so

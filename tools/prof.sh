@@ -30,4 +30,6 @@ mkdir -p $OUT/commit
 cp $OUT/summary.txt $OUT/commit/${TAG}_rocprofv3_summary.txt
 cp $OUT/pmc.json $OUT/commit/${TAG}_pmc.json
 cp $OUT/trace/*kernel_stats.csv $OUT/commit/${TAG}_kernel_stats.csv 2>/dev/null
-grep "^{" $OUT/trace_bench.log | tail -1 > $OUT/commit/${TAG}_bench_under_trace.json
+# the bench line of the traced run: JSON for bench.py, the last text lines for the other drivers
+if grep -q "^{" $OUT/trace_bench.log; then grep "^{" $OUT/trace_bench.log | tail -1 > $OUT/commit/${TAG}_bench_under_trace.json
+else grep -v "amdgpu.ids\|rocprofv3\|^[EWI][0-9]\{8\}\|^$" $OUT/trace_bench.log | tail -4 > $OUT/commit/${TAG}_under_trace.txt; fi
