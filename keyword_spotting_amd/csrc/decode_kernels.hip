@@ -159,14 +159,33 @@ __global__ void __launch_bounds__(256) vad_kernel(const float* __restrict__ pcm,
 template <typename SampleT>
 __global__ void __launch_bounds__(256) vad_gate_kernel(const SampleT* __restrict__ pcm, int N, float thres, float* __restrict__ pcm_f32,
                                                        const uint8_t* __restrict__ restart, uint8_t* __restrict__ silent,
-                                                       uint8_t* __restrict__ reset) {
+                                                       uint8_t* __restrict__ reset, const float* __restrict__ carry, int n_carry,
+                                                       float* __restrict__ next, int n_next) {
     const int b = blockIdx.x;
-    const float total = block_abs_sum<SampleT>(pcm + (size_t)b * N, N, sizeof(SampleT) == 2 ? pcm_f32 + (size_t)b * N : nullptr);
+    const SampleT* row = pcm + (size_t)b * N;
+    const float total = block_abs_sum<SampleT>(row, N, sizeof(SampleT) == 2 ? pcm_f32 + (size_t)b * N : nullptr);
     if (threadIdx.x == 0) {
         const uint8_t quiet = total > thres ? 0 : 1;
         silent[b] = quiet;
         reset[b] = (quiet || (restart && restart[b])) ? 1 : 0;
     }
+    // next carry = the last n_next samples of [carry | chunk] (detector.py:181-183), while the chunk is hot in the cache
+    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
+    for (int j = threadIdx.x; j < n_next; j += 256) {
+        const int i = n_carry + N - n_next + j;
+        next[(size_t)b * n_next + j] = i < n_carry ? carry[(size_t)b * n_carry + i] : (float)row[i - n_carry] * kScale;
+    }
+}
+
+hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,
+                           uint8_t* silent, uint8_t* reset, const float* carry, int n_carry, float* next, int n_next, hipStream_t st) {
+    if (pcm_int16)
+        hipLaunchKernelGGL(vad_gate_kernel<int16_t>, dim3(B), dim3(256), 0, st, static_cast<const int16_t*>(pcm), N, thres, pcm_f32,
+                           restart, silent, reset, carry, n_carry, next, n_next);
+    else
+        hipLaunchKernelGGL(vad_gate_kernel<float>, dim3(B), dim3(256), 0, st, static_cast<const float*>(pcm), N, thres, pcm_f32,
+                           restart, silent, reset, carry, n_carry, next, n_next);
+    return hipGetLastError();
 }
 
 __global__ void state_passthrough_kernel(const float* __restrict__ state_in, float* __restrict__ state_out, const uint8_t* __restrict__ reset,
@@ -179,17 +198,6 @@ __global__ void state_passthrough_kernel(const float* __restrict__ state_in, flo
 hipError_t launch_state_passthrough(const float* state_in, float* state_out, const uint8_t* reset, int L, int B, int H, hipStream_t st) {
     const size_t n = (size_t)L * B * H;
     hipLaunchKernelGGL(state_passthrough_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, state_in, state_out, reset, L, B, H);
-    return hipGetLastError();
-}
-
-hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,
-                           uint8_t* silent, uint8_t* reset, hipStream_t st) {
-    if (pcm_int16)
-        hipLaunchKernelGGL(vad_gate_kernel<int16_t>, dim3(B), dim3(256), 0, st, static_cast<const int16_t*>(pcm), N, thres, pcm_f32,
-                           restart, silent, reset);
-    else
-        hipLaunchKernelGGL(vad_gate_kernel<float>, dim3(B), dim3(256), 0, st, static_cast<const float*>(pcm), N, thres, pcm_f32,
-                           restart, silent, reset);
     return hipGetLastError();
 }
 

@@ -1294,10 +1294,9 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
         // clean_state() + prob_queue.clear() when silent, the samples are carried (:179-183 keeps all of them), sess.run over
         // zero frames returns the state unchanged and an empty softmax, which takes a slot of the window (:195) before the
         // windowed decode (:197-201).
-        hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset, st);
+        hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset,
+                                            h->n_carry ? carry : nullptr, h->n_carry, next, total, st);
         if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
-        e = kws::launch_carry_tail(h->n_carry ? carry : chunk, h->n_carry, chunk, n, next, total, B, st);
-        if (e != hipSuccess) return hip_fail(e, "launch carry_tail");
         int rc = kws_step(h->model, nullptr, h->state, nullptr, nullptr, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, 0, st);
         if (rc != KWS_OK) return rc;
         rc = kws_window_step(h->win, nullptr, 0, h->silent, h->label, hit, h->restart, st);
@@ -1305,10 +1304,12 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
         h->n_carry = total; h->cur ^= 1;
         return KWS_OK;
     }
-    hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset, st);
-    if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
     const int keep = (total - fft) % hop + (fft - hop);                                  // detector.py:181-182
-    int rc = kws_frontend_run_carry(h->fe, h->n_carry ? carry : nullptr, h->n_carry, chunk, n, B, h->mel, next, keep, st);
+    // one pass over the new chunk: int16 -> float, vad + masks, and the next carry (its last `keep` samples of [carry | chunk])
+    hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset,
+                                        h->n_carry ? carry : nullptr, h->n_carry, next, keep, st);
+    if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
+    int rc = kws_frontend_run_carry(h->fe, h->n_carry ? carry : nullptr, h->n_carry, chunk, n, B, h->mel, nullptr, 0, st);
     if (rc != KWS_OK) return rc;
     const int T = kws_frontend_frames(&fc, total);
     rc = kws_step(h->model, h->mel, h->state, nullptr, h->softmax, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, T, st);

@@ -183,8 +183,10 @@ hipError_t launch_vad(const float* pcm, int B, int N, float thres, uint8_t* spee
 
 // state_out = reset[b] ? 0 : state_in for [L,B,H] (a kws_step over zero frames; in-place allowed)
 hipError_t launch_state_passthrough(const float* state_in, float* state_out, const uint8_t* reset, int L, int B, int H, hipStream_t st);
+// ... and, fused into the same pass, the next sample carry: next [B,n_next] = the last n_next samples of [carry | chunk]
+// (n_next = 0: none)
 hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,
-                           uint8_t* silent, uint8_t* reset, hipStream_t st);
+                           uint8_t* silent, uint8_t* reset, const float* carry, int n_carry, float* next, int n_next, hipStream_t st);
 
 // octbit_kernels.hip
 hipError_t launch_octbit_matmul(const float* x, const int8_t* Wq, float scale_w, const float* bias,

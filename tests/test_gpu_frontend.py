@@ -404,3 +404,66 @@ def test_stream_handle_outliving_its_model_or_frontend_fails_cleanly():
     model.close()
     with pytest.raises(_lib.InvalidArgumentError):
         mgr.feed_pcm(pcm, fe2)
+
+
+@pytest.mark.parametrize("fft,hop,n_mel", [(256, 128, 40), (320, 160, 24), (480, 160, 60), (64, 16, 8)])
+def test_other_frame_lengths_run_the_dense_dft_kernel(fft, hop, n_mel):
+    """Only the reference's 400-sample frames take the FFT kernel; every other multiple of 16 keeps the dense-DFT kernel
+    (frontend_kernels.hip) -- same oracle, same tolerance."""
+    cfg, fe = _frontend(fft_size=fft, hop_size=hop, n_mel=n_mel)
+    rng = np.random.default_rng(300 + fft)
+    pcm = (rng.standard_normal((3, 5 * fft + 77)) * 0.1).astype(np.float32)
+    got = fe.forward(torch.from_numpy(pcm)).cpu().numpy()
+    want = F.melspec(pcm, n_fft=fft, hop=hop, n_mels=n_mel)
+    assert got.shape == want.shape and want.shape[1] == 1 + (pcm.shape[1] - fft) // hop
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n_mel", [40, 60, 13])
+def test_fft_kernel_and_dense_kernel_agree_on_400_sample_frames(n_mel, monkeypatch):
+    """The 16 x 25 FFT (fft_frontend.hip) and the dense DFT it replaced compute the same mel spectrogram: both within the
+    oracle tolerance, and within it of each other -- incl. a filter count that is not a multiple of 4 (scalar stores),
+    a batch whose frame count is not a multiple of the 16-frame workgroup tile, and the carry seam."""
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.frontend import MelFrontend
+    cfg = get_config(n_mel=n_mel)
+    fast = MelFrontend(cfg)
+    monkeypatch.setenv("KWS_FRONTEND_DENSE", "1")
+    dense = MelFrontend(cfg)
+    monkeypatch.delenv("KWS_FRONTEND_DENSE")
+    rng = np.random.default_rng(310 + n_mel)
+    for batch, n in ((7, 3600), (1, 400), (3, 400 + 160 * 16), (5, 6000)):
+        pcm = (rng.standard_normal((batch, n)) * 0.1).astype(np.float32)
+        a = fast.forward(torch.from_numpy(pcm)).cpu().numpy()
+        b = dense.forward(torch.from_numpy(pcm)).cpu().numpy()
+        want = F.melspec(pcm, n_mels=n_mel)
+        scale = np.abs(want).max()
+        assert np.abs(a - want).max() < 2e-5 * scale and np.abs(b - want).max() < 2e-5 * scale
+        assert np.abs(a - b).max() < 2e-5 * scale
+    carry = torch.from_numpy(rng.standard_normal((4, 333)).astype(np.float32)).cuda()
+    chunk = torch.from_numpy(rng.standard_normal((4, 3600)).astype(np.float32)).cuda()
+    ma, na = fast.forward_carry(carry, chunk, 300)
+    mb, nb = dense.forward_carry(carry, chunk, 300)
+    assert torch.equal(na, nb) and (ma - mb).abs().max() < 2e-5 * mb.abs().max()
+    assert torch.equal(ma, fast.forward(torch.cat([carry, chunk], 1)))          # seam path == contiguous path, bit for bit
+
+
+def test_frontend_full_size_chunk_properties():
+    """4096 streams x one 225 ms chunk with carried samples (the bench shape): sampled streams against the oracle, every
+    stream's result independent of the batch it sits in (bitwise), linear in the input scale, finite."""
+    cfg, fe = _frontend()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    carry = torch.randn(4096, 240, generator=gen, device="cuda") * 0.1
+    chunk = torch.randn(4096, 3600, generator=gen, device="cuda") * 0.1
+    mel, nxt = fe.forward_carry(carry, chunk, 240)
+    assert mel.shape == (4096, 22, 40) and bool(torch.isfinite(mel).all())
+    data = torch.cat([carry, chunk], 1)
+    assert torch.equal(nxt, data[:, -240:])
+    pick = [0, 1, 15, 16, 17, 2047, 2048, 4094, 4095]
+    want = F.melspec(data[pick].cpu().numpy(), n_mels=40)
+    got = mel[pick].cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+    sub = fe.forward(data[pick].contiguous())                   # other batch composition, other tiles, no seam path
+    assert torch.equal(sub, mel[pick])
+    twice, _ = fe.forward_carry(carry * 2, chunk * 2, 240)      # |rfft| and the projection are homogeneous of degree 1: exact in fp32
+    assert torch.equal(twice, mel * 2)
