@@ -79,6 +79,7 @@ constexpr float kW16c1 = 0.92387953251128674f, kW16s1 = 0.38268343236508977f;   
 constexpr int kRowBytes = 128;                 // one (k1, frame) row: 16 complex values over n2
 constexpr int kPlaneBytes = 16 * kRowBytes;    // one k1: 16 frames
 constexpr int kFftLds = 13 * kPlaneBytes;      // 26,624 B per workgroup: six workgroups per CU
+constexpr int kMelRegs = 24;                   // basis fragments (4-bin groups) of a mel tile that wait in registers
 constexpr int kSpecRows = 208;                 // spectrum rows (bins 0..200 + zero padding) of 16 frames: 13,312 B of the same space
 
 }  // namespace
@@ -222,13 +223,12 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
     }
     // basis fragments of this wave's mel tile: the first kMelRegs groups of its run wait in registers (the loads fly while the
     // spectrum is written and the workgroup meets at the barrier); a longer run streams the rest
-    constexpr int kMelRegs = 24;
     const int lo4 = w < MT ? p.mel_lo[w] : 0, n = w < MT ? p.mel_cnt[w] : 0;   // first 4-bin group, number of groups (multiple of 4; zero-padded table)
     const float* A = p.melw + ((size_t)(w < MT ? p.mel_off[w] : 0) * 64 + lane);
     float a[kMelRegs];
-    if (n > 0) {
+    if (n > 0) {         // every tile's table holds at least kMelRegs groups (zero padded): no clamping, one base + immediate offsets
 #pragma unroll
-        for (int e = 0; e < kMelRegs; ++e) a[e] = A[(size_t)(e < n ? e : n - 1) * 64];
+        for (int e = 0; e < kMelRegs; ++e) a[e] = A[e * 64];
     }
     KWS_FE_STAMP(4);
     lds_barrier();             // every wave has read its planes: the spectrum takes their place

@@ -1125,13 +1125,14 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
             cnt = (cnt + 3) & ~3;                       // the kernel works in fours: the extra groups carry zero weights and stay
             if (lo + cnt > 52) lo = 52 - cnt;           // inside the 52 groups (208 rows) of the spectrum block
             f->mel_lo[mt] = lo; f->mel_cnt[mt] = cnt; f->mel_off[mt] = groups_total;
-            host.resize(host.size() + (size_t)cnt * 64, 0.f);
+            const int stored = std::max(cnt, 24);       // the kernel preloads 24 groups per tile unconditionally (kMelRegs): zero padded
+            host.resize(host.size() + (size_t)stored * 64, 0.f);
             for (int e = 0; e < cnt; ++e)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int g = lane >> 4, m = 16 * mt + (lane & 15), b = 4 * (lo + e) + g;
                     if (m < cfg->n_mel && b <= 200) host[f->fft_mel_off + ((size_t)(groups_total + e) * 64) + lane] = f->basis[(size_t)m * NF + b];
                 }
-            groups_total += cnt;
+            groups_total += stored;
         }
         const char* dense = getenv("KWS_FRONTEND_DENSE");      // A/B switch: the dense-DFT kernel also handles 400
         f->use_fft = !(dense && dense[0] == '1');
