@@ -12,6 +12,8 @@
 // At bf16 MFMA rates (16 cycles per 16x16x32) both layers' weights fit the register file (84 operands x 4
 // VGPRs = 336 of 512) and the matrix work of a frame is ~1.4k cycles, so the whole stack runs FUSED in one
 // launch with no inter-layer HBM scratch; activations, LDS exchange and barriers dominate.
+#include <cstdlib>
+
 #include "gru_device.h"
 
 namespace kws {
@@ -432,6 +434,298 @@ gru_stack_bf16(const GruBf16Params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Two waves per SIMD, LAYER-SPECIALISED (NL == 2): waves 0..3 run layer 0, waves 4..7 layer 1, each on its 32 units as
+// above, in the same skewed schedule -- iteration i = layer 0 on frame i+1 beside layer 1 on frame i, two workgroup
+// barriers.  A lone wave issues a VALU instruction only every ~4.7 cycles, two waves on a SIMD one every ~2.3
+// (tools/ubench/valu_rate.hip), and bf16 MFMAs do not share the FP32 datapath with the VALU: the frame is mostly
+// activations, conversions, LDS round trips and fences (tools/ubench/waves_per_simd_bf16.hip: MFMAs are a quarter of
+// it), so a layer-0 wave and a layer-1 wave that share a SIMD fill each other's gaps.  (The fp32 kernels gain nothing
+// from a second wave -- waves_per_simd.hip: their MFMAs and VALU share one pipe.)  256 registers per wave: layer 0 keeps
+// its 36 operands in registers, layer 1 its 32 gate operands; layer 1's 16 candidate operands stream from LDS (64 KiB).
+// ------------------------------------------------------------------------------------------------------------
+template <int KX0>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gru_stack_bf16_ls(const GruBf16Params p) {
+    constexpr int H = 128, NL = 2;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int layer = wave >> 2, w = wave & 3;             // w: this wave's 32 units within its layer
+    const int lane = tid & 63, g = lane >> 4, s = lane & 15;
+    const int group = blockIdx.x;
+    const int b_raw = group * kStreamsPerGroup + s;
+    const bool bvalid = b_raw < p.B;
+    const int b = bvalid ? b_raw : p.B - 1;
+    const int T = p.T;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* hb = reinterpret_cast<u32x4*>(smem);             // [NL][4 chunks][64]  h_{t-1} (bf16)
+    u32x4* rhb = hb + NL * 4 * 64;                           // [NL][4][64]         r (.) h_{t-1}
+    u32x4* xsb = rhb + NL * 4 * 64;                          // [KX0][64]           mel frame (bf16), zero padded
+    u32x4* wc1 = xsb + KX0 * 64;                             // [4 waves][2 tiles][8 chunks][64]  layer 1 candidate operands
+    float* biasl = reinterpret_cast<float*>(wc1 + 4 * 2 * 8 * 64); // [NL][3][128]
+    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + NL * 3 * H));
+
+    constexpr int KC0 = KX0 + 4, KC1 = 8;
+    // ---- LDS init (all eight waves): biases, zeroed mel staging, layer 1's candidate operands, initial state -------
+    for (int i = tid; i < NL * 3 * H; i += 512) biasl[i] = p.bias[i / (3 * H)][i % (3 * H)];
+    for (int i = tid; i < KX0 * 64; i += 512) xsb[i] = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < 4 * 2 * 8 * 64; i += 512) {
+        const int ln = i & 63, c = (i >> 6) & 7, j = (i >> 9) & 1, ww = i >> 10;
+        wc1[i] = reinterpret_cast<const u32x4*>(p.w[1])[(((2 * ww + j) * 3 + 2) * KC1 + c) * 64 + ln];
+    }
+    const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
+    const int len_s = p.seq_len ? p.seq_len[b] : T;
+    f32x4 hreg[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        hreg[j] = do_reset ? splat4(0.f) : ld4(p.state_in + ((size_t)layer * p.B + b) * H + (2 * w + j) * 16 + 4 * g);
+    hb[(layer * 4 + w) * 64 + lane] = (u32x4){pack_bf16(hreg[0][0], hreg[0][1]), pack_bf16(hreg[0][2], hreg[0][3]),
+                                               pack_bf16(hreg[1][0], hreg[1][1]), pack_bf16(hreg[1][2], hreg[1][3])};
+    if (tid < 16) {
+        const int bb = group * kStreamsPerGroup + tid;
+        int pw = -1;
+        if (bb < p.B && p.epi.prev_word && !(p.reset && p.reset[bb])) pw = p.epi.prev_word[bb];
+        epi.carry[tid] = pw;
+    }
+    const f32x4* bl = reinterpret_cast<const f32x4*>(biasl + layer * 3 * H);
+    // the epilogue's barriers are workgroup barriers: layer 0's waves keep step with them
+    auto flush_due = [&](int i) { return i >= 0 && ((((i + 1) & (kRingFrames - 1)) == 0) || i == T - 1); };
+
+    if (layer == 0) {
+        // ================= layer 0: frame i+1 in iteration i =================
+        bf16x8 w0[2][3][KC0];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < KC0; ++c) {
+                    w0[j][q][c] = as_bf16x8(reinterpret_cast<const u32x4*>(p.w[0])[(((2 * w + j) * 3 + q) * KC0 + c) * 64 + lane]);
+                    asm volatile("" : "+a"(w0[j][q][c]));
+                }
+        asm volatile("s_nop 7" ::: "memory");
+        // mel: wave w fetches streams 4w..4w+3 (one dwordx4 per lane), rounds to bf16, scatters into the B-operand image
+        const int XQ = p.I / 4;
+        const int xl_row = lane / XQ, xl_q = lane % XQ;
+        const bool xl_active = lane < 4 * XQ;
+        const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
+        const float4* xl_src = reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * T * p.I) + xl_q;
+        unsigned* xs_dst = reinterpret_cast<unsigned*>(xsb) +
+                           (((xl_q * 4) / 32) * 64 + (((xl_q * 4) % 32) / 8) * 16 + (4 * w + xl_row)) * 4 + ((xl_q * 4) % 8) / 2;
+        float4 fl_a = make_float4(0.f, 0.f, 0.f, 0.f), fl_b = fl_a;
+        auto fetch = [&](float4& r, int t_req) { if (xl_active) r = xl_src[(size_t)(t_req < T ? t_req : T - 1) * XQ]; };
+        auto commit = [&](const float4& r) {
+            if (xl_active) *reinterpret_cast<uint2*>(xs_dst) = make_uint2(pack_bf16(r.x, r.y), pack_bf16(r.z, r.w));
+        };
+        __syncthreads();
+        if (T > 0) {
+            fetch(fl_a, 0);
+            commit(fl_a);                 // x(0)
+            fetch(fl_b, 1);
+            fetch(fl_a, 2);
+        }
+        __syncthreads();
+        auto iteration = [&](int i, float4& fl_commit) {
+            bf16x8 xB[KX0], h0B[4];
+#pragma unroll
+            for (int c = 0; c < KX0; ++c) xB[c] = as_bf16x8(xsb[c * 64 + lane]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) h0B[m] = as_bf16x8(hb[(0 * 4 + m) * 64 + lane]);
+            f32x4 r0[2], u0[2], c0[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (2 * w + j) * 4 + g;
+                r0[j] = bl[0 * 32 + o]; u0[j] = bl[1 * 32 + o]; c0[j] = bl[2 * 32 + o];
+            }
+            mfma_prefence(r0[0], u0[0], r0[1], u0[1]);
+            mfma_prefence(c0[0], c0[1]);
+#pragma unroll
+            for (int c = 0; c < KX0; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    KWS_MFMA_BF16_A(r0[j], w0[j][0][c], xB[c]);
+                    KWS_MFMA_BF16_A(u0[j], w0[j][1][c], xB[c]);
+                    KWS_MFMA_BF16_A(c0[j], w0[j][2][c], xB[c]);
+                }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    KWS_MFMA_BF16_A(r0[j], w0[j][0][KX0 + m], h0B[m]);
+                    KWS_MFMA_BF16_A(u0[j], w0[j][1][KX0 + m], h0B[m]);
+                }
+            mfma_fence(r0[0], u0[0], r0[1], u0[1]);
+            f32x4 rh0[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 a = sigmoid2((f32x2){r0[j][2 * h2], r0[j][2 * h2 + 1]}) * (f32x2){hreg[j][2 * h2], hreg[j][2 * h2 + 1]};
+                    rh0[j][2 * h2] = a.x; rh0[j][2 * h2 + 1] = a.y;
+                }
+            rhb[(0 * 4 + w) * 64 + lane] = (u32x4){pack_bf16(rh0[0][0], rh0[0][1]), pack_bf16(rh0[0][2], rh0[0][3]),
+                                                    pack_bf16(rh0[1][0], rh0[1][1]), pack_bf16(rh0[1][2], rh0[1][3])};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 a = sigmoid2((f32x2){u0[j][2 * h2], u0[j][2 * h2 + 1]});
+                    u0[j][2 * h2] = a.x; u0[j][2 * h2 + 1] = a.y;
+                }
+            lds_barrier();            // #1: both r(.)h visible; hb / xsb fully consumed
+            mfma_prefence(c0[0], c0[1]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const bf16x8 rB0 = as_bf16x8(rhb[(0 * 4 + m) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) KWS_MFMA_BF16_A(c0[j], w0[j][2][KX0 + m], rB0);
+            }
+            mfma_fence(c0[0], c0[1]);
+            const unsigned live0 = (i + 1 < T && i + 1 < len_s) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 c = tanh2((f32x2){c0[j][2 * h2], c0[j][2 * h2 + 1]});
+                    const f32x2 uu = {u0[j][2 * h2], u0[j][2 * h2 + 1]};
+                    const f32x2 hh = {hreg[j][2 * h2], hreg[j][2 * h2 + 1]};
+                    const f32x2 hn = (1.0f - uu) * c + uu * hh;
+                    hreg[j][2 * h2] = bitsel(live0, hn.x, hh.x);
+                    hreg[j][2 * h2 + 1] = bitsel(live0, hn.y, hh.y);
+                }
+            hb[(0 * 4 + w) * 64 + lane] = (u32x4){pack_bf16(hreg[0][0], hreg[0][1]), pack_bf16(hreg[0][2], hreg[0][3]),
+                                                   pack_bf16(hreg[1][0], hreg[1][1]), pack_bf16(hreg[1][2], hreg[1][3])};
+            commit(fl_commit);        // x(i+2)
+            fetch(fl_commit, i + 4);
+            lds_barrier();            // #2: h0(i+1), h1(i), x(i+2), partial logits visible
+            // the epilogue (fold, softmax, decode rule, stores) runs on layer 0's waves: they carry 36 MFMAs and no LDS-fed
+            // operands per iteration against layer 1's 49, so the tail work goes where the slack is
+            if (i >= 0 && w == (i & 3)) epilogue_fold(epi, i, lane);
+            if (flush_due(i)) {
+                const int t0 = i & ~(kRingFrames - 1);
+                lds_barrier();
+                epilogue_flush(p.epi, epi, group, t0, i - t0 + 1, w, lane, i == T - 1);
+            }
+        };
+        for (int i = -1; i < T; i += 2) {
+            iteration(i, fl_b);
+            if (i + 1 < T) iteration(i + 1, fl_a);
+        }
+    } else {
+        // ================= layer 1: frame i in iteration i, the dense layer and the epilogue =================
+        bf16x8 w1[2][2][KC1];            // gates only: [tile][r|u][chunk]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < KC1; ++c) {
+                    w1[j][q][c] = as_bf16x8(reinterpret_cast<const u32x4*>(p.w[1])[(((2 * w + j) * 3 + q) * KC1 + c) * 64 + lane]);
+                    asm volatile("" : "+a"(w1[j][q][c]));
+                }
+        asm volatile("s_nop 7" ::: "memory");
+        const bf16x8 wfc = as_bf16x8(reinterpret_cast<const u32x4*>(p.wfc)[w * 64 + lane]);
+        f32x4 bfc4 = splat4(0.f);
+        if (w == 0) bfc4 = ld4(p.bfc + 4 * g);
+        const u32x4* wcl = wc1 + (size_t)w * 2 * 8 * 64 + lane;      // [tile][chunk][64]
+        __syncthreads();
+        __syncthreads();
+        auto iteration = [&](int i) {
+            bf16x8 h0B[4], h1B[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { h0B[m] = as_bf16x8(hb[(0 * 4 + m) * 64 + lane]); h1B[m] = as_bf16x8(hb[(1 * 4 + m) * 64 + lane]); }
+            f32x4 r1[2], u1[2], c1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (2 * w + j) * 4 + g;
+                r1[j] = bl[0 * 32 + o]; u1[j] = bl[1 * 32 + o]; c1[j] = bl[2 * 32 + o];
+            }
+            // candidate x-part on h0(i): operands from LDS (builtin MFMAs: the compiler tracks these hazards itself)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) c1[j] = mfma_bf16(as_bf16x8(wcl[(j * 8 + m) * 64]), h0B[m], c1[j]);
+            mfma_prefence(r1[0], u1[0], r1[1], u1[1]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    KWS_MFMA_BF16_A(r1[j], w1[j][0][m], h0B[m]);
+                    KWS_MFMA_BF16_A(u1[j], w1[j][1][m], h0B[m]);
+                }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    KWS_MFMA_BF16_A(r1[j], w1[j][0][4 + m], h1B[m]);
+                    KWS_MFMA_BF16_A(u1[j], w1[j][1][4 + m], h1B[m]);
+                }
+            mfma_fence(r1[0], u1[0], r1[1], u1[1]);
+            f32x4 rh1[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 a = sigmoid2((f32x2){r1[j][2 * h2], r1[j][2 * h2 + 1]}) * (f32x2){hreg[j][2 * h2], hreg[j][2 * h2 + 1]};
+                    rh1[j][2 * h2] = a.x; rh1[j][2 * h2 + 1] = a.y;
+                }
+            rhb[(1 * 4 + w) * 64 + lane] = (u32x4){pack_bf16(rh1[0][0], rh1[0][1]), pack_bf16(rh1[0][2], rh1[0][3]),
+                                                    pack_bf16(rh1[1][0], rh1[1][1]), pack_bf16(rh1[1][2], rh1[1][3])};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 a = sigmoid2((f32x2){u1[j][2 * h2], u1[j][2 * h2 + 1]});
+                    u1[j][2 * h2] = a.x; u1[j][2 * h2 + 1] = a.y;
+                }
+            lds_barrier();            // #1
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const bf16x8 rB1 = as_bf16x8(rhb[(1 * 4 + m) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) c1[j] = mfma_bf16(as_bf16x8(wcl[(j * 8 + 4 + m) * 64]), rB1, c1[j]);
+            }
+            const unsigned live1 = (i >= 0 && i < len_s) ? 0xffffffffu : 0u;
+            f32x4 hout[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2 c = tanh2((f32x2){c1[j][2 * h2], c1[j][2 * h2 + 1]});
+                    const f32x2 uu = {u1[j][2 * h2], u1[j][2 * h2 + 1]};
+                    const f32x2 hh = {hreg[j][2 * h2], hreg[j][2 * h2 + 1]};
+                    const f32x2 hn = (1.0f - uu) * c + uu * hh;
+                    hreg[j][2 * h2] = bitsel(live1, hn.x, hh.x);
+                    hreg[j][2 * h2 + 1] = bitsel(live1, hn.y, hh.y);
+                    hout[j][2 * h2] = bitsel(live1, hn.x, 0.f);
+                    hout[j][2 * h2 + 1] = bitsel(live1, hn.y, 0.f);
+                }
+            hb[(1 * 4 + w) * 64 + lane] = (u32x4){pack_bf16(hreg[0][0], hreg[0][1]), pack_bf16(hreg[0][2], hreg[0][3]),
+                                                   pack_bf16(hreg[1][0], hreg[1][1]), pack_bf16(hreg[1][2], hreg[1][3])};
+            if (i >= 0) {
+                u32x4 hBv = (u32x4){pack_bf16(hout[0][0], hout[0][1]), pack_bf16(hout[0][2], hout[0][3]),
+                                    pack_bf16(hout[1][0], hout[1][1]), pack_bf16(hout[1][2], hout[1][3])};
+                asm volatile("s_nop 3" : "+v"(hBv));
+                const f32x4 accf = mfma_bf16(wfc, as_bf16x8(hBv), bfc4);
+                if (g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
+            }
+            lds_barrier();            // #2
+            if (flush_due(i)) { lds_barrier(); lds_barrier(); }     // the fold and the flush by layer 0's waves
+        };
+        for (int i = -1; i < T; ++i) iteration(i);
+    }
+    if (bvalid) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<f32x4*>(p.state_out + ((size_t)layer * p.B + b) * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
+    }
+}
+
+size_t gru_bf16_ls_lds_bytes(int kx0) {
+    return (size_t)(2 * 2 * 4 * 64 + kx0 * 64 + 4 * 2 * 8 * 64) * 16 + (size_t)2 * 3 * 128 * 4 + kEpilogueLdsBytes;
+}
+
 size_t gru_bf16_lds_bytes(int kx0, int nl) {
     return (size_t)(2 * nl * 4 * 64 + kx0 * 64) * 16 + (size_t)nl * 3 * 128 * 4 + kEpilogueLdsBytes;
 }
@@ -453,7 +747,26 @@ static hipError_t launch_bf16(const GruBf16Params& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int KX0>
+static hipError_t launch_bf16_ls(const GruBf16Params& p, hipStream_t st) {
+    const size_t lds = gru_bf16_ls_lds_bytes(KX0);
+    static LdsGrant granted;
+    {
+        const hipError_t e = grant_dynamic_lds(gru_stack_bf16_ls<KX0>, granted, lds);
+        if (e != hipSuccess) return e;
+    }
+    const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
+    hipLaunchKernelGGL((gru_stack_bf16_ls<KX0>), dim3(groups), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st) {
+    // two layers: the layer-specialised 8-wave kernel (KWS_BF16_WAVES=4 keeps the 4-wave kernel for A/B)
+    static const bool four = [] { const char* e = getenv("KWS_BF16_WAVES"); return e && e[0] == '4'; }();
+    if (nl == 2 && !four) {
+        if (kx0 == 1) return launch_bf16_ls<1>(p, st);
+        if (kx0 == 2) return launch_bf16_ls<2>(p, st);
+    }
     if (kx0 == 1 && nl == 1) return launch_bf16<1, 1>(p, st);
     if (kx0 == 1 && nl == 2) return launch_bf16<1, 2>(p, st);
     if (kx0 == 2 && nl == 1) return launch_bf16<2, 1>(p, st);
