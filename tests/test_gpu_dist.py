@@ -35,9 +35,11 @@ def test_two_ranks_on_one_gpu_drive_the_hip_library_and_aggregate():
     assert two["config"]["kernel"] != "stub" and two["config"]["streams_per_gpu"] == 1024
     assert two["roofline"]["launches"] == 3 and two["roofline"]["kernel_ms"] > 0
     # the same total work (2 x 1024 streams) in one process on the same GPU: the two ranks share the chip, so the aggregate
-    # must land near the single-process figure -- far off would mean a rank did not run, ran twice, or the reduction is wrong
+    # must land within 15 % of the single-process figure -- far off would mean a rank did not run, ran twice, or the reduction is wrong
     one = _bench("--gpus", "1", "--batch", "2048", *common)
     assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
     ratio = two["value"] / one["value"]
-    assert 0.6 < ratio < 1.25, (two["value"], one["value"])
+    print("two ranks on one GPU: %.1f M frames/s aggregate, one process on the same total batch: %.1f M (ratio %.2f)"
+          % (two["value"] / 1e6, one["value"] / 1e6, ratio))
+    assert 0.85 < ratio < 1.15, (two["value"], one["value"])          # measured 0.98: the two processes' kernels share the chip
     assert two["ms_per_step"] > 0 and abs(two["value"] - 2 * 1024 * 300 / (two["ms_per_step"] * 1e-3)) < 1e-6 * two["value"]
