@@ -5,6 +5,7 @@
 // HBM-bound byte work: one thread walks one stream's [T,C] window (the lockout / loose-mode rules
 // are sequential in t); a warp-wide layout would buy nothing at 24 B per frame.
 #include "kws_internal.h"
+#include "vad_device.h"
 
 namespace kws {
 
@@ -96,51 +97,6 @@ __global__ void ctc_predict_kernel(const int32_t* __restrict__ words, const int3
     hit[b] = found;
 }
 
-// sum_n |x[n]| of one row by a 256-thread block in fp32 (utils/basic_vad.py:17-18).  ONE summation order for every caller
-// and every buffer -- kws_vad and the stream manager's gate kernel must take identical decisions, whatever the alignment of
-// the row: thread t owns the groups of four samples t, t + 256, ...; a group is summed (|a|+|b|)+(|c|+|d|) and added to the
-// thread's partial sum, then wave shuffles, then the four wave totals.  Aligned rows fetch a group with one 8/16-byte load,
-// unaligned rows and the tail group (N % 4 samples, padded with +0) sample by sample: the arithmetic is the same.
-template <typename SampleT>
-__device__ __forceinline__ float block_abs_sum(const SampleT* __restrict__ x, int N, float* __restrict__ widened) {
-    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;      // detector.py:40-43: int16 -> [-1, 1)
-    float acc = 0.f;
-    const bool vec = (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(SampleT) - 1)) == 0;
-    const bool wvec = widened && (reinterpret_cast<uintptr_t>(widened) & 15) == 0;
-    const int full = N / 4;
-    for (int i = threadIdx.x; i < (N + 3) / 4; i += 256) {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (i < full && vec) {
-            if constexpr (sizeof(SampleT) == 2) {
-                const short4 q = reinterpret_cast<const short4*>(x)[i];
-                v[0] = (float)q.x * kScale; v[1] = (float)q.y * kScale; v[2] = (float)q.z * kScale; v[3] = (float)q.w * kScale;
-            } else {
-                const float4 q = reinterpret_cast<const float4*>(x)[i];
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * i + e < N) v[e] = (float)x[4 * i + e] * kScale;
-        }
-        if (widened) {
-            if (i < full && wvec) {
-                reinterpret_cast<float4*>(widened)[i] = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * i + e < N) widened[4 * i + e] = v[e];
-            }
-        }
-        acc += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    return (part[0] + part[1]) + (part[2] + part[3]);         // valid in thread 0
-}
-
 __global__ void __launch_bounds__(256) vad_kernel(const float* __restrict__ pcm, int N, float thres,
                                                   uint8_t* __restrict__ speech, float* __restrict__ abs_sum) {
     const int b = blockIdx.x;
@@ -164,17 +120,9 @@ __global__ void __launch_bounds__(256) vad_gate_kernel(const SampleT* __restrict
     const int b = blockIdx.x;
     const SampleT* row = pcm + (size_t)b * N;
     const float total = block_abs_sum<SampleT>(row, N, sizeof(SampleT) == 2 ? pcm_f32 + (size_t)b * N : nullptr);
-    if (threadIdx.x == 0) {
-        const uint8_t quiet = total > thres ? 0 : 1;
-        silent[b] = quiet;
-        reset[b] = (quiet || (restart && restart[b])) ? 1 : 0;
-    }
-    // next carry = the last n_next samples of [carry | chunk] (detector.py:181-183), while the chunk is hot in the cache
-    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
-    for (int j = threadIdx.x; j < n_next; j += 256) {
-        const int i = n_carry + N - n_next + j;
-        next[(size_t)b * n_next + j] = i < n_carry ? carry[(size_t)b * n_carry + i] : (float)row[i - n_carry] * kScale;
-    }
+    if (threadIdx.x == 0) vad_masks(total, thres, b, restart, silent, reset);
+    // next carry, while the chunk is hot in the cache
+    carry_tail<SampleT>(carry + (size_t)b * n_carry, n_carry, row, N, next + (size_t)b * n_next, n_next);
 }
 
 hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,

@@ -18,6 +18,7 @@
 // v_mfma_f32_16x16x4_f32; the order of the bins along K is free, the basis fragments are packed to match (kws_api.hip).
 // ~9 kflop per frame on the VALU instead of the 100 kflop of the dense contraction.
 #include "gru_device.h"
+#include "vad_device.h"
 
 #pragma clang fp contract(off)      // only the fmaf() written below fuse: every frame sees one fixed instruction sequence
 
@@ -90,7 +91,11 @@ constexpr int kSpecRows = 208;                 // spectrum rows (bins 0..200 + z
 // weights are not all zero: filters are contiguous in frequency, so tile m needs one contiguous run of 4-bin groups --
 // 52 MFMAs per 16 frames for 40 filters where the dense product takes 156.  Wave m = tile m.
 // 26 KiB of LDS per workgroup (the spectrum reuses the transpose planes): six workgroups = 24 waves per CU.
-template <int MT>
+// SampleT: float samples, or int16 PCM as the sound card delivers it (detector.py:40-43,74-79: scaled by 2^-15 on load --
+// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along -- workgroup k first
+// takes the vad sum of stream k's new samples (the masks silent / reset) and writes its next sample carry; that pass is
+// HBM-bound where the transform is issue-bound, and it saves a launch (kws_stream_feed).
+template <int MT, typename SampleT, bool GATE>
 __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams p) {
     __shared__ __attribute__((aligned(16))) char lds[kFftLds];
     const int tid = threadIdx.x;
@@ -99,6 +104,18 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
     const int hi = lane >> 4, lo = lane & 15;          // stage 1: (frame j of 4, n2); stage 2 / MFMA: (g, frame f of 16)
     const unsigned total = (unsigned)p.B * (unsigned)p.T;
     const unsigned f0 = blockIdx.x * 16u;
+    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
+    const SampleT* chunk_all = sizeof(SampleT) == 2 ? reinterpret_cast<const SampleT*>(p.pcm_i16) : reinterpret_cast<const SampleT*>(p.pcm);
+    const int n_chunk = p.n_samples - p.n_carry;
+    if constexpr (GATE) {
+        for (int bs = blockIdx.x; bs < p.B; bs += gridDim.x) {
+            const SampleT* row = chunk_all + (size_t)bs * n_chunk;
+            const float sum = block_abs_sum<SampleT>(row, n_chunk, nullptr);
+            if (tid == 0) vad_masks(sum, p.vad_thres, bs, p.restart, p.silent, p.reset);
+            carry_tail<SampleT>(p.carry + (size_t)bs * p.n_carry, p.n_carry, row, n_chunk, p.next + (size_t)bs * p.n_next, p.n_next);
+            __syncthreads();             // block_abs_sum's staging words are free again
+        }
+    }
 #ifdef KWS_FE_TIMING       // tools/ubench/fe_phases.hip: s_memtime at the phase boundaries of every wave
 #define KWS_FE_STAMP(i) do { if (lane == 0) p.timing[((size_t)blockIdx.x * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -116,12 +133,20 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
         const int st = (int)(fidx - sb * (unsigned)p.T);
         // the signal of stream sb is carry[sb] (n_carry samples, may be 0) followed by pcm[sb] (detector.py:179)
         const float* xc_ = p.carry + (size_t)sb * p.n_carry;
-        const float* xp_ = p.pcm + (size_t)sb * (p.n_samples - p.n_carry);
+        const SampleT* xp_ = chunk_all + (size_t)sb * n_chunk;
         const int s0 = st * p.hop + n2;
         float x[25];
         const bool seam = s0 - n2 < p.n_carry && s0 - n2 + 400 > p.n_carry;
-        if (!__builtin_amdgcn_ballot_w64(seam)) {
-            const float* src = s0 - n2 >= p.n_carry ? xp_ + (s0 - p.n_carry) : xc_ + s0;
+        const unsigned long long any_seam = __builtin_amdgcn_ballot_w64(seam);
+        const unsigned long long any_carry = __builtin_amdgcn_ballot_w64(s0 - n2 < p.n_carry);
+        if (!any_carry) {
+            // every frame of this wave lies in the new samples (all but the first rounds of a chunk)
+            const SampleT* src = xp_ + (s0 - p.n_carry);
+#pragma unroll
+            for (int n1 = 0; n1 < 25; ++n1) x[n1] = (float)src[16 * n1] * kScale;
+        } else if (!any_seam && sizeof(SampleT) == 4) {
+            // whole frames, some in the carried samples, some in the new ones; one float array each
+            const float* src = s0 - n2 >= p.n_carry ? reinterpret_cast<const float*>(xp_) + (s0 - p.n_carry) : xc_ + s0;
 #pragma unroll
             for (int n1 = 0; n1 < 25; ++n1) x[n1] = src[16 * n1];
         } else {
@@ -129,8 +154,7 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
 #pragma unroll
             for (int n1 = 0; n1 < 25; ++n1) {
                 const int idx = s0 + 16 * n1;
-                const float* src = idx < p.n_carry ? xc_ + idx : xp_ + (idx - p.n_carry);
-                x[n1] = *src;
+                x[n1] = idx < p.n_carry ? xc_[idx] : (float)xp_[idx - p.n_carry] * kScale;
             }
         }
         // W400^{n2 k1}, k1 = 1..12, for this lane's n2 (cos, sin): [12][16] float2
@@ -293,17 +317,23 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
     KWS_FE_STAMP(7);
 }
 
-hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st) {
-    const long long total = (long long)B * p.T;        // < 2^31 (checked by the caller)
-    const unsigned grid = (unsigned)((total + 15) / 16);
+template <typename SampleT, bool GATE>
+static hipError_t launch_fft400_tiles(const FrontendParams& p, unsigned grid, hipStream_t st) {
     switch (p.mel_tiles) {
-        case 1: hipLaunchKernelGGL(mel_fft400_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL(mel_fft400_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL(mel_fft400_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
-        case 4: hipLaunchKernelGGL(mel_fft400_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((mel_fft400_kernel<1, SampleT, GATE>), dim3(grid), dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((mel_fft400_kernel<2, SampleT, GATE>), dim3(grid), dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((mel_fft400_kernel<3, SampleT, GATE>), dim3(grid), dim3(256), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((mel_fft400_kernel<4, SampleT, GATE>), dim3(grid), dim3(256), 0, st, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st) {
+    const long long total = (long long)B * p.T;        // < 2^31 (checked by the caller)
+    const unsigned grid = (unsigned)((total + 15) / 16);
+    if (p.pcm_i16) return p.gate ? launch_fft400_tiles<int16_t, true>(p, grid, st) : launch_fft400_tiles<int16_t, false>(p, grid, st);
+    return p.gate ? launch_fft400_tiles<float, true>(p, grid, st) : launch_fft400_tiles<float, false>(p, grid, st);
 }
 
 }  // namespace kws

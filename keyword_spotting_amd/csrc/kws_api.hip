@@ -1162,15 +1162,32 @@ int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host) {
     return KWS_OK;
 }
 
+// the head of a stream-manager iteration that the FFT front-end can take along in its own launch (kws_stream_feed)
+struct FrontGate {
+    const int16_t* pcm_i16;        // int16 input read in place (chunk is then ignored), or null
+    float vad_thres;
+    const uint8_t* restart;
+    uint8_t *silent, *reset;
+    float* next;
+    int n_next;
+};
+static bool frontend_fuses_gate(kws_frontend_handle h, int B, int T) { return h->use_fft && T > 0 && (long long)B * T < (1LL << 31); }
+
 static int frontend_run_impl(kws_frontend_handle h, const float* carry, int n_carry, const float* chunk, int n_chunk, int B,
-                             float* mel, void* stream) {
+                             float* mel, void* stream, const FrontGate* gate = nullptr) {
     const int n_samples = n_carry + n_chunk;
     const int T = kws_frontend_frames(&h->cfg, n_samples);
     if (B == 0 || T == 0) return KWS_OK;
-    if (!chunk || !mel || (n_carry > 0 && !carry)) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if ((!chunk && !(gate && gate->pcm_i16)) || !mel || (n_carry > 0 && !carry)) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
     if ((long long)B * T > (1LL << 36)) return fail(KWS_ERR_UNSUPPORTED, "B*T=%lld frames exceed the grid limit", (long long)B * T);
     kws::FrontendParams p = {};
     p.pcm = chunk; p.carry = n_carry > 0 ? carry : chunk; p.mel = mel;
+    if (gate) {
+        if (!frontend_fuses_gate(h, B, T)) return fail(KWS_ERR_UNSUPPORTED, "internal: the gate rides only on the FFT front-end");
+        p.gate = 1; p.pcm_i16 = gate->pcm_i16; p.vad_thres = gate->vad_thres; p.restart = gate->restart;
+        p.silent = gate->silent; p.reset = gate->reset; p.next = gate->next; p.n_next = gate->n_next;
+        if (n_carry == 0) p.carry = gate->next;     // never dereferenced (n_carry == 0), only has to be a float pointer
+    }
     p.dft = h->d_tables + h->dft_off; p.melw = h->d_tables + h->melw_off;
     p.n_samples = n_samples; p.n_carry = n_carry; p.T = T; p.fft = h->cfg.fft_size; p.hop = h->cfg.hop_size; p.n_mel = h->cfg.n_mel;
     p.nf_tiles = h->nf_tiles; p.mel_tiles = h->mel_tiles; p.kc4 = h->kc4; p.B = B;
@@ -1306,13 +1323,21 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
         return KWS_OK;
     }
     const int keep = (total - fft) % hop + (fft - hop);                                  // detector.py:181-182
-    // one pass over the new chunk: int16 -> float, vad + masks, and the next carry (its last `keep` samples of [carry | chunk])
-    hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset,
-                                        h->n_carry ? carry : nullptr, h->n_carry, next, keep, st);
-    if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
-    int rc = kws_frontend_run_carry(h->fe, h->n_carry ? carry : nullptr, h->n_carry, chunk, n, B, h->mel, nullptr, 0, st);
-    if (rc != KWS_OK) return rc;
     const int T = kws_frontend_frames(&fc, total);
+    int rc;
+    if (frontend_fuses_gate(h->fe, B, T)) {
+        // ONE launch: vad + masks and the next carry ride on the FFT front-end, which reads the PCM -- int16 as it is -- in place
+        FrontGate gate = {pcm_int16 ? static_cast<const int16_t*>(pcm) : nullptr, h->vad_thres, h->restart, h->silent, h->reset, next, keep};
+        rc = frontend_run_impl(h->fe, h->n_carry ? carry : nullptr, h->n_carry, pcm_int16 ? nullptr : chunk, n, B, h->mel, st, &gate);
+        if (rc != KWS_OK) return rc;
+    } else {
+        // other frame lengths: one pass over the new chunk (int16 -> float, vad + masks, next carry), then the dense-DFT kernel
+        hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset,
+                                            h->n_carry ? carry : nullptr, h->n_carry, next, keep, st);
+        if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
+        rc = kws_frontend_run_carry(h->fe, h->n_carry ? carry : nullptr, h->n_carry, chunk, n, B, h->mel, nullptr, 0, st);
+        if (rc != KWS_OK) return rc;
+    }
     rc = kws_step(h->model, h->mel, h->state, nullptr, h->softmax, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, T, st);
     if (rc != KWS_OK) return rc;
     rc = kws_window_step(h->win, h->softmax, T, h->silent, h->label, hit, h->restart, st);

@@ -148,7 +148,17 @@ hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st);
 
 // PCM -> mel front-end (frontend_kernels.hip)
 struct FrontendParams {
-    const float* pcm;    // [B, n_samples - n_carry]  the new samples
+    const float* pcm;    // [B, n_samples - n_carry]  the new samples (float input)
+    const int16_t* pcm_i16;   // fft_frontend.hip only: int16 PCM instead (scaled by 2^-15 as RingBuffer.get does), pcm unused
+    // fft_frontend.hip only, the head of a stream-manager iteration fused into the same launch (gate != 0): vad over the new
+    // samples -> silent / reset masks, and the next sample carry (the last n_next samples of [carry | chunk])
+    int gate;
+    float vad_thres;
+    const uint8_t* restart;
+    uint8_t* silent;
+    uint8_t* reset;
+    float* next;
+    int n_next;
     const float* carry;  // [B, n_carry] samples carried over from the previous chunk (n_carry may be 0)
     float* mel;          // [B, T, n_mel]
     const float* dft;    // [nf_tiles x (cos|sin) x parity][kc4][64][4]  A fragments: bins 0..fft/4 over the folded samples of one parity
@@ -161,7 +171,7 @@ struct FrontendParams {
 };
 hipError_t launch_mel_frontend(const FrontendParams& p, int B, hipStream_t st);
 // fft 400 only (fft_frontend.hip): p.dft = twiddles [12][16] (cos, sin), p.melw = basis fragments [tile][group of its run][64]
-hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st);
+hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st);      // honours p.pcm_i16 and p.gate
 hipError_t launch_carry_tail(const float* carry, int n_carry, const float* chunk, int n_chunk, float* next, int n_next, int B,
                              hipStream_t st);
 

@@ -1,0 +1,75 @@
+// vad(data, thres) = sum(|data|) > thres (utils/basic_vad.py:17-18): the one summation every kernel of the library uses
+// (kws_vad, the stream manager's gate kernel, the gate fused into the FFT front-end), so that all of them take the same
+// decision on the same samples.
+#pragma once
+#include "kws_internal.h"
+
+namespace kws {
+
+// sum_n |x[n]| of one row by a 256-thread block in fp32 (utils/basic_vad.py:17-18).  ONE summation order for every caller
+// and every buffer -- kws_vad and the stream manager's gate kernel must take identical decisions, whatever the alignment of
+// the row: thread t owns the groups of four samples t, t + 256, ...; a group is summed (|a|+|b|)+(|c|+|d|) and added to the
+// thread's partial sum, then wave shuffles, then the four wave totals.  Aligned rows fetch a group with one 8/16-byte load,
+// unaligned rows and the tail group (N % 4 samples, padded with +0) sample by sample: the arithmetic is the same.
+template <typename SampleT>
+__device__ __forceinline__ float block_abs_sum(const SampleT* __restrict__ x, int N, float* __restrict__ widened) {
+    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;      // detector.py:40-43: int16 -> [-1, 1)
+    float acc = 0.f;
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(SampleT) - 1)) == 0;
+    const bool wvec = widened && (reinterpret_cast<uintptr_t>(widened) & 15) == 0;
+    const int full = N / 4;
+    for (int i = threadIdx.x; i < (N + 3) / 4; i += 256) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i < full && vec) {
+            if constexpr (sizeof(SampleT) == 2) {
+                const short4 q = reinterpret_cast<const short4*>(x)[i];
+                v[0] = (float)q.x * kScale; v[1] = (float)q.y * kScale; v[2] = (float)q.z * kScale; v[3] = (float)q.w * kScale;
+            } else {
+                const float4 q = reinterpret_cast<const float4*>(x)[i];
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * i + e < N) v[e] = (float)x[4 * i + e] * kScale;
+        }
+        if (widened) {
+            if (i < full && wvec) {
+                reinterpret_cast<float4*>(widened)[i] = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * i + e < N) widened[4 * i + e] = v[e];
+            }
+        }
+        acc += (fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3]));
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return (part[0] + part[1]) + (part[2] + part[3]);         // valid in thread 0
+}
+
+
+// the masks one loop iteration of detector.py:158-209 consumes, from the chunk's vad sum: silent (-> the decode window is
+// cleared before the chunk is added, :171-177) and reset = silent | restart (-> the GRU starts this chunk from zero)
+__device__ __forceinline__ void vad_masks(float total, float thres, int b, const uint8_t* __restrict__ restart,
+                                          uint8_t* __restrict__ silent, uint8_t* __restrict__ reset) {
+    const uint8_t quiet = total > thres ? 0 : 1;
+    silent[b] = quiet;
+    reset[b] = (quiet || (restart && restart[b])) ? 1 : 0;
+}
+
+// next carry = the last n_next samples of [carry | chunk] (detector.py:181-183), by the 256 threads of a block
+template <typename SampleT>
+__device__ __forceinline__ void carry_tail(const float* __restrict__ carry, int n_carry, const SampleT* __restrict__ chunk, int n_chunk,
+                                           float* __restrict__ next, int n_next) {
+    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
+    for (int j = threadIdx.x; j < n_next; j += 256) {
+        const int i = n_carry + n_chunk - n_next + j;
+        next[j] = i < n_carry ? carry[i] : (float)chunk[i - n_carry] * kScale;
+    }
+}
+
+}  // namespace kws
