@@ -4,7 +4,8 @@
 #include <cstdio>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// KIND 0: v_fma_f32, 1: v_add_f32, 2: v_pk_fma_f32, 3: v_pk_add_f32, 4: v_pk_mul_f32, 5: v_sqrt_f32, 6: v_mov_b32 (dpp-free)
+// KIND 0: v_fma_f32, 1: v_add_f32, 2: v_pk_fma_f32, 3: v_pk_add_f32, 4: v_pk_mul_f32, 5: v_sqrt_f32, 6: v_xor_b32,
+// 7: v_pk_mul_lo_u16, 8: v_pk_mad_i16 clamp, 9: v_dot2_i32_i16, 10: v_med3_i32, 11: v_dot4_i32_i8, 12: v_exp_f32, 13: v_cvt_pk_bf16_f32
 template <int KIND>
 __global__ void __launch_bounds__(1024) k(const float* __restrict__ src, float* __restrict__ dst, long long* cyc, int iters) {
     float v[16];
@@ -26,6 +27,13 @@ __global__ void __launch_bounds__(1024) k(const float* __restrict__ src, float* 
                 if (KIND == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
                 if (KIND == 5) asm volatile("v_sqrt_f32 %0, %0" : "+v"(v[i]));
                 if (KIND == 6) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+                if (KIND == 7) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+                if (KIND == 8) asm volatile("v_pk_mad_i16 %0, %0, %1, %0 clamp" : "+v"(v[i]) : "v"(c));
+                if (KIND == 9) asm volatile("v_dot2_i32_i16 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
+                if (KIND == 10) asm volatile("v_med3_i32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(c));
+                if (KIND == 11) asm volatile("v_dot4_i32_i8 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
+                if (KIND == 12) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+                if (KIND == 13) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -60,7 +68,7 @@ void run(const char* name, K kern, int threads, int per_iter, const float* src, 
     long long c = 0; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     const int wps = threads / 256;
     const double n = (double)iters * per_iter;            // instructions per wave
-    printf("%-14s %d wave/SIMD: %.2f s_memtime ticks per instr per wave; wall %.3f ms -> %.2f ns per instr per SIMD (x2.4 = %.2f cyc @2.4GHz)\n",
+    printf("%-20s %d wave/SIMD: %.2f s_memtime ticks per instr per wave; wall %.3f ms -> %.2f ns per instr per SIMD (x2.4 = %.2f cyc @2.4GHz)\n",
            name, wps, c / n, ms, ms * 1e6 / (n * wps), ms * 1e6 / (n * wps) * 2.4);
 }
 
@@ -76,6 +84,13 @@ int main() {
         run("v_pk_mul_f32", k<4>, threads, 64, src, dst, cyc);
         run("v_sqrt_f32", k<5>, threads, 128, src, dst, cyc);
         run("v_xor_b32", k<6>, threads, 128, src, dst, cyc);
+        run("v_pk_mul_lo_u16", k<7>, threads, 128, src, dst, cyc);
+        run("v_pk_mad_i16 clamp", k<8>, threads, 128, src, dst, cyc);
+        run("v_dot2_i32_i16", k<9>, threads, 128, src, dst, cyc);
+        run("v_med3_i32", k<10>, threads, 128, src, dst, cyc);
+        run("v_dot4_i32_i8", k<11>, threads, 128, src, dst, cyc);
+        run("v_exp_f32", k<12>, threads, 128, src, dst, cyc);
+        run("v_cvt_pk_bf16_f32", k<13>, threads, 128, src, dst, cyc);
     }
     return 0;
 }
