@@ -43,3 +43,44 @@ def test_two_ranks_on_one_gpu_drive_the_hip_library_and_aggregate():
           % (two["value"] / 1e6, one["value"] / 1e6, ratio))
     assert 0.85 < ratio < 1.15, (two["value"], one["value"])          # measured 0.98: the two processes' kernels share the chip
     assert two["ms_per_step"] > 0 and abs(two["value"] - 2 * 1024 * 300 / (two["ms_per_step"] * 1e-3)) < 1e-6 * two["value"]
+
+
+@pytest.mark.parametrize("world,precision", [(2, "fp32"), (3, "fp32"), (2, "bf16")])
+def test_sharded_results_equal_the_unsharded_run_bitwise(world, precision, tmp_path):
+    """the same seeded global batch partitioned over `world` ranks (ragged: 37 streams) gives, shard by
+    shard, exactly the bytes of the one-process run -- streams are independent and a stream's result does not depend on
+    the batch it sits in, so partitioning is invisible.  Real library, one process per rank, all on cuda:0."""
+    import socket
+    import numpy as np
+    import torch
+    from keyword_spotting_amd import get_config, weights
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    total, frames = 37, 23
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_shard_worker.py"), str(tmp_path), str(total), str(frames), precision]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    cfg = get_config(precision=precision)
+    model = DeployModel(cfg, weights.init_weights(cfg, seed=0))
+    gen = torch.Generator().manual_seed(1234)
+    mel = (torch.randn(total, frames, cfg.n_mel, generator=gen).abs() * 2)
+    state = 0.1 * torch.randn(cfg.num_layers, total, cfg.hidden_size, generator=gen)
+    want = model.forward(mel, state, prev_word=model.fresh_prev_word(total))
+    covered = 0
+    for rank in range(world):
+        z = np.load(str(tmp_path / ("shard_%d.npz" % rank)))
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert lo == covered and hi > lo
+        covered = hi
+        np.testing.assert_array_equal(z["logits"], want["logits"][lo:hi].cpu().numpy())
+        np.testing.assert_array_equal(z["softmax"], want["softmax"][lo:hi].cpu().numpy())
+        np.testing.assert_array_equal(z["state"], want["state"][:, lo:hi].cpu().numpy())
+        np.testing.assert_array_equal(z["tokens"], want["tokens"][lo:hi].cpu().numpy())
+    assert covered == total
