@@ -92,8 +92,8 @@ constexpr int kSpecRows = 208;                 // spectrum rows (bins 0..200 + z
 // 52 MFMAs per 16 frames for 40 filters where the dense product takes 156.  Wave m = tile m.
 // 26 KiB of LDS per workgroup (the spectrum reuses the transpose planes): six workgroups = 24 waves per CU.
 // SampleT: float samples, or int16 PCM as the sound card delivers it (detector.py:40-43,74-79: scaled by 2^-15 on load --
-// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along -- workgroup k first
-// takes the vad sum of stream k's new samples (the masks silent / reset) and writes its next sample carry; that pass is
+// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along -- one wave of workgroup
+// k takes the vad sum of stream k's new samples (the masks silent / reset) and writes its next sample carry; that pass is
 // HBM-bound where the transform is issue-bound, and it saves a launch (kws_stream_feed).
 template <int MT, typename SampleT, bool GATE>
 __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams p) {
@@ -107,15 +107,6 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
     constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
     const SampleT* chunk_all = sizeof(SampleT) == 2 ? reinterpret_cast<const SampleT*>(p.pcm_i16) : reinterpret_cast<const SampleT*>(p.pcm);
     const int n_chunk = p.n_samples - p.n_carry;
-    if constexpr (GATE) {
-        for (int bs = blockIdx.x; bs < p.B; bs += gridDim.x) {
-            const SampleT* row = chunk_all + (size_t)bs * n_chunk;
-            const float sum = block_abs_sum<SampleT>(row, n_chunk, nullptr);
-            if (tid == 0) vad_masks(sum, p.vad_thres, bs, p.restart, p.silent, p.reset);
-            carry_tail<SampleT>(p.carry + (size_t)bs * p.n_carry, p.n_carry, row, n_chunk, p.next + (size_t)bs * p.n_next, p.n_next);
-            __syncthreads();             // block_abs_sum's staging words are free again
-        }
-    }
 #ifdef KWS_FE_TIMING       // tools/ubench/fe_phases.hip: s_memtime at the phase boundaries of every wave
 #define KWS_FE_STAMP(i) do { if (lane == 0) p.timing[((size_t)blockIdx.x * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -311,6 +302,19 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (c0 + e < p.n_mel) out[c0 + e] = r[e];
+            }
+        }
+    }
+    if constexpr (GATE) {
+        // The head of the stream-manager iteration, by the wave with the least to do after the last barrier (no mel tile
+        // for 40 filters): workgroup k takes stream k's vad sum -- wave_abs_sum: the bits of kws_vad's block sum -- the
+        // masks and the next carry while the other waves finish the projection.  No workgroup barrier: wave-private.
+        if (w == 3) {
+            for (int bs = blockIdx.x; bs < p.B; bs += gridDim.x) {
+                const SampleT* row = chunk_all + (size_t)bs * n_chunk;
+                const float sum = wave_abs_sum<SampleT>(row, n_chunk, lane);
+                if (lane == 0) vad_masks(sum, p.vad_thres, bs, p.restart, p.silent, p.reset);
+                carry_tail<SampleT>(p.carry + (size_t)bs * p.n_carry, p.n_carry, row, n_chunk, p.next + (size_t)bs * p.n_next, p.n_next, lane, 64);
             }
         }
     }

@@ -52,6 +52,46 @@ __device__ __forceinline__ float block_abs_sum(const SampleT* __restrict__ x, in
 }
 
 
+// The same sum, the same association of every addition -- hence the same bits -- by ONE wave: lane l plays threads l, 64 + l,
+// 128 + l, 192 + l of the block above (four partial sums), each "wave" of them is folded by the same shuffle tree, and the
+// four totals meet in the same order.  For kernels that have a wave to spare but no workgroup barrier.  Valid in lane 0.
+template <typename SampleT>
+__device__ __forceinline__ float wave_abs_sum(const SampleT* __restrict__ x, int N, int lane) {
+    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(SampleT) - 1)) == 0;
+    const int full = N / 4, groups = (N + 3) / 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < groups; base += 256) {
+        float v[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = base + 64 * t + lane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[t][e] = 0.f;
+            if (i < full && vec) {
+                if constexpr (sizeof(SampleT) == 2) {
+                    const short4 q = reinterpret_cast<const short4*>(x)[i];
+                    v[t][0] = (float)q.x * kScale; v[t][1] = (float)q.y * kScale; v[t][2] = (float)q.z * kScale; v[t][3] = (float)q.w * kScale;
+                } else {
+                    const float4 q = reinterpret_cast<const float4*>(x)[i];
+                    v[t][0] = q.x; v[t][1] = q.y; v[t][2] = q.z; v[t][3] = q.w;
+                }
+            } else if (i < groups) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * i + e < N) v[t][e] = (float)x[4 * i + e] * kScale;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (base + 64 * t + lane < groups) acc[t] += (fabsf(v[t][0]) + fabsf(v[t][1])) + (fabsf(v[t][2]) + fabsf(v[t][3]));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        for (int off = 32; off > 0; off >>= 1) acc[t] += __shfl_down(acc[t], off);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 // the masks one loop iteration of detector.py:158-209 consumes, from the chunk's vad sum: silent (-> the decode window is
 // cleared before the chunk is added, :171-177) and reset = silent | restart (-> the GRU starts this chunk from zero)
 __device__ __forceinline__ void vad_masks(float total, float thres, int b, const uint8_t* __restrict__ restart,
@@ -61,12 +101,12 @@ __device__ __forceinline__ void vad_masks(float total, float thres, int b, const
     reset[b] = (quiet || (restart && restart[b])) ? 1 : 0;
 }
 
-// next carry = the last n_next samples of [carry | chunk] (detector.py:181-183), by the 256 threads of a block
+// next carry = the last n_next samples of [carry | chunk] (detector.py:181-183), by `nthreads` threads (index `thread`)
 template <typename SampleT>
 __device__ __forceinline__ void carry_tail(const float* __restrict__ carry, int n_carry, const SampleT* __restrict__ chunk, int n_chunk,
-                                           float* __restrict__ next, int n_next) {
+                                           float* __restrict__ next, int n_next, int thread = threadIdx.x, int nthreads = 256) {
     constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
-    for (int j = threadIdx.x; j < n_next; j += 256) {
+    for (int j = thread; j < n_next; j += nthreads) {
         const int i = n_carry + n_chunk - n_next + j;
         next[j] = i < n_carry ? carry[i] : (float)chunk[i - n_carry] * kScale;
     }
