@@ -226,3 +226,48 @@ def test_window_kernel_against_the_oracle_queue(window_chunks, frames):
                 fired += 1
     assert fired >= 3
     lib.kws_window_destroy(win)
+
+
+def test_stream_manager_takes_kws_vad_s_decision_on_borderline_chunks():
+    """The gate that rides on the front-end launch sums |x| with one wave (vad_device.h:wave_abs_sum), kws_vad with a
+    256-thread block: same association, same bits.  64 chunks are scaled by bisection until kws_vad's sum sits within an
+    ulp or two of the threshold -- half just above, half just below; any difference in summation order would flip some of
+    them, and a flipped decision zeroes (or fails to zero) the recurrent state."""
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.basic_vad import vad
+    from keyword_spotting_amd.detector import HotwordDetector, StreamManager
+    from keyword_spotting_amd.frontend import MelFrontend
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg = get_config()
+    fe = MelFrontend(cfg)
+    w = G.init_weights(seed=5)
+    b, n, thres = 64, 3600, 30.0
+    rng = np.random.default_rng(99)
+    base = torch.from_numpy((rng.standard_normal((b, n)) * rng.uniform(0.01, 0.3, (b, 1))).astype(np.float32)).cuda()
+    lo = torch.zeros(b, 1, device="cuda")
+    hi = torch.full((b, 1), 1000.0, device="cuda")
+    for _ in range(60):                                   # float32 bisection on the scale: lo -> silent, hi -> speech
+        mid = (lo + hi) / 2
+        speech = vad(base * mid, thres).bool().unsqueeze(1)
+        hi = torch.where(speech, mid, hi)
+        lo = torch.where(speech, lo, mid)
+    scale = torch.where((torch.arange(b, device="cuda") % 2 == 0).unsqueeze(1), hi, lo)
+    edge = (base * scale).contiguous()
+    want_speech, sums = vad(edge, thres, return_sum=True)
+    assert int(want_speech.sum()) == b // 2 and float((sums - thres).abs().max()) < 1e-4     # really at the edge
+    loud = torch.from_numpy((rng.standard_normal((b, n)) * 0.2).astype(np.float32)).cuda()
+    det, mgr = HotwordDetector(DeployModel(cfg, w), batch=b, label="1233"), StreamManager(DeployModel(cfg, w), b, label="1233")
+    for chunk in (loud, edge, loud, edge):
+        det.feed_pcm(chunk, fe)
+        mgr.feed_pcm(chunk, fe)
+        assert torch.equal(mgr.state, det.state)
+    # and the decision is visible: a silent edge chunk restarts its stream from the zero state, a speech one does not
+    kept, zeroed = StreamManager(DeployModel(cfg, w), b, label="1233"), StreamManager(DeployModel(cfg, w), b, label="1233")
+    kept.feed_pcm(loud, fe)
+    zeroed.feed_pcm(loud, fe)
+    assert kept.state.abs().sum() > 0
+    zeroed.state.zero_()                                   # what clean_state() does, for every stream
+    kept.feed_pcm(edge, fe)
+    zeroed.feed_pcm(edge, fe)
+    same = (kept.state == zeroed.state).all(0).all(1).cpu().numpy()
+    np.testing.assert_array_equal(same, ~want_speech.bool().cpu().numpy())
