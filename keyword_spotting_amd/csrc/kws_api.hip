@@ -238,7 +238,7 @@ inline int bf16_unit(int m, int g, int j) { return 32 * m + (j < 4 ? 4 * g + j :
 
 extern "C" {
 
-const char* kws_version(void) { return "kws_amd 0.2 (gfx950)"; }
+const char* kws_version(void) { return "kws_amd 0.3 (gfx950)"; }
 const char* kws_last_error(void) { return g_last_error.c_str(); }
 size_t kws_sizeof_config(void) { return sizeof(kws_config); }
 size_t kws_sizeof_frontend_config(void) { return sizeof(kws_frontend_config); }
