@@ -13,10 +13,10 @@
 // Stage 2: for k1 = 0..12 a 16-point complex FFT over n2 (radix 4 x 4) gives X[k1 + 25 k2], k2 = 0..15.  Those 208 values
 //   hold every bin 0..200 exactly once: k <= 200 directly, k > 200 as the mirror 400 - k (|X[400-k]| = |X[k]|; the bins of
 //   residue 13..24 mod 25), and k1 = 0, k2 >= 9 are duplicates that the mel table zeroes.
-// Between the stages the 13 x 16 complex values of a frame cross lanes through LDS (one transpose; a workgroup is 16 frames).
-// In stage 2 lane = (g, frame f of 16) takes k1 = 4q + g in pass q (= wave q), so its sixteen magnitudes are -- as they stand in registers -- the B operands (k = g, n = f) of the mel projection on
-// v_mfma_f32_16x16x4_f32; the order of the bins along K is free, the basis fragments are packed to match (kws_api.hip).
-// ~9 kflop per frame on the VALU instead of the 100 kflop of the dense contraction.
+// Between the stages the 13 x 16 complex values of a frame cross lanes through LDS (one transpose; a workgroup is 16
+// frames).  In stage 2 lane = (g, frame f of 16) takes k1 = 4q + g in pass q (= wave q); the magnitudes return to LDS in BIN
+// order, where the mel projection (v_mfma_f32_16x16x4_f32 over 4-bin groups) only touches the blocks of the basis that are
+// not all zero.  ~9 kflop per frame on the VALU instead of the 100 kflop of the dense contraction.
 #include "gru_device.h"
 #include "vad_device.h"
 
