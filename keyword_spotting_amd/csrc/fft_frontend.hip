@@ -95,8 +95,11 @@ constexpr int kSpecRows = 208;                 // spectrum rows (bins 0..200 + z
 // read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along -- one wave of workgroup
 // k takes the vad sum of stream k's new samples (the masks silent / reset) and writes its next sample carry; that pass is
 // HBM-bound where the transform is issue-bound, and it saves a launch (kws_stream_feed).
+#ifndef KWS_FE_OCC
+#define KWS_FE_OCC 6          // workgroups per CU the register allocation aims at (tools/build_variant.sh -DKWS_FE_OCC=n for A/B)
+#endif
 template <int MT, typename SampleT, bool GATE>
-__global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams p) {
+__global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const FrontendParams p) {
     __shared__ __attribute__((aligned(16))) char lds[kFftLds];
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,9 +152,13 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
             }
         }
         // W400^{n2 k1}, k1 = 1..12, for this lane's n2 (cos, sin): [12][16] float2
-        float2 tw[12];
+        float2 tw[12];          // table: [6 pairs of k1][16 n2] float4 = (cos, sin) of k1 = 2i+1 and 2i+2: six 16-byte loads
 #pragma unroll
-        for (int k = 0; k < 12; ++k) tw[k] = reinterpret_cast<const float2*>(p.dft)[k * 16 + n2];
+        for (int k = 0; k < 6; ++k) {
+            const f32x4 t = reinterpret_cast<const f32x4*>(p.dft)[k * 16 + n2];
+            tw[2 * k] = make_float2(t[0], t[1]);
+            tw[2 * k + 1] = make_float2(t[2], t[3]);
+        }
 #ifdef KWS_FE_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KWS_FE_STAMP(1);
@@ -239,11 +246,15 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
     // basis fragments of this wave's mel tile: the first kMelRegs groups of its run wait in registers (the loads fly while the
     // spectrum is written and the workgroup meets at the barrier); a longer run streams the rest
     const int lo4 = w < MT ? p.mel_lo[w] : 0, n = w < MT ? p.mel_cnt[w] : 0;   // first 4-bin group, number of groups (multiple of 4; zero-padded table)
-    const float* A = p.melw + ((size_t)(w < MT ? p.mel_off[w] : 0) * 64 + lane);
+    // table: [tile][group / 4][64 lanes] float4 (the fragments of four consecutive groups side by side): one 16-byte load each
+    const f32x4* A = reinterpret_cast<const f32x4*>(p.melw) + ((size_t)(w < MT ? p.mel_off[w] : 0) / 4 * 64 + lane);
     float a[kMelRegs];
     if (n > 0) {         // every tile's table holds at least kMelRegs groups (zero padded): no clamping, one base + immediate offsets
 #pragma unroll
-        for (int e = 0; e < kMelRegs; ++e) a[e] = A[e * 64];
+        for (int e4 = 0; e4 < kMelRegs / 4; ++e4) {
+            const f32x4 v = A[e4 * 64];
+            a[4 * e4] = v[0]; a[4 * e4 + 1] = v[1]; a[4 * e4 + 2] = v[2]; a[4 * e4 + 3] = v[3];
+        }
     }
     KWS_FE_STAMP(4);
     lds_barrier();             // every wave has read its planes: the spectrum takes their place
@@ -285,10 +296,11 @@ __global__ void __launch_bounds__(256, 6) mel_fft400_kernel(const FrontendParams
         });
         for (int e = kMelRegs; e < n; e += 4) {
             const float b0 = Sg[e * 64], b1 = Sg[(e + 1) * 64], b2 = Sg[(e + 2) * 64], b3 = Sg[(e + 3) * 64];
-            acc0 = mfma4(A[(size_t)e * 64], b0, acc0);
-            acc1 = mfma4(A[(size_t)(e + 1) * 64], b1, acc1);
-            acc0 = mfma4(A[(size_t)(e + 2) * 64], b2, acc0);
-            acc1 = mfma4(A[(size_t)(e + 3) * 64], b3, acc1);
+            const f32x4 v = A[(size_t)(e / 4) * 64];
+            acc0 = mfma4(v[0], b0, acc0);
+            acc1 = mfma4(v[1], b1, acc1);
+            acc0 = mfma4(v[2], b2, acc0);
+            acc1 = mfma4(v[3], b3, acc1);
         }
         const f32x4 r = acc0 + acc1;
         // D[filter 16w + 4g + e][frame f]

@@ -1104,13 +1104,14 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
         // fft_frontend.hip: the 16 x 25 real FFT.  Twiddles W400^{n2 k1} as (cos, sin) [k1 = 1..12][n2 = 0..15].  Mel basis as MFMA
         // A fragments over 4-bin groups (k = g <-> bin 4 group + g): per tile of 16 filters only the contiguous run of groups that
         // carry a non-zero weight, padded to a multiple of four; bins > 200 are zero rows.
-        f->fft_tw_off = host.size();
+        f->fft_tw_off = host.size();                        // [6 pairs (k1 = 2i+1, 2i+2)][16 n2][cos, sin, cos, sin]
         host.resize(host.size() + 12 * 16 * 2, 0.f);
         for (int k1 = 1; k1 <= 12; ++k1)
             for (int n2 = 0; n2 < 16; ++n2) {
                 const double ang = two_pi * (double)(n2 * k1) / 400.0;
-                host[f->fft_tw_off + ((size_t)(k1 - 1) * 16 + n2) * 2 + 0] = (float)std::cos(ang);
-                host[f->fft_tw_off + ((size_t)(k1 - 1) * 16 + n2) * 2 + 1] = (float)std::sin(ang);
+                const size_t at = f->fft_tw_off + ((size_t)((k1 - 1) / 2) * 16 + n2) * 4 + 2 * ((k1 - 1) & 1);
+                host[at + 0] = (float)std::cos(ang);
+                host[at + 1] = (float)std::sin(ang);
             }
         f->fft_mel_off = host.size();
         int groups_total = 0;
@@ -1127,10 +1128,11 @@ int kws_frontend_create(const kws_frontend_config* cfg, kws_frontend_handle* out
             f->mel_lo[mt] = lo; f->mel_cnt[mt] = cnt; f->mel_off[mt] = groups_total;
             const int stored = std::max(cnt, 24);       // the kernel preloads 24 groups per tile unconditionally (kMelRegs): zero padded
             host.resize(host.size() + (size_t)stored * 64, 0.f);
-            for (int e = 0; e < cnt; ++e)
+            for (int e = 0; e < cnt; ++e)                 // [tile][e / 4][lane][e % 4]: four groups' fragments per 16-byte load
                 for (int lane = 0; lane < 64; ++lane) {
                     const int g = lane >> 4, m = 16 * mt + (lane & 15), b = 4 * (lo + e) + g;
-                    if (m < cfg->n_mel && b <= 200) host[f->fft_mel_off + ((size_t)(groups_total + e) * 64) + lane] = f->basis[(size_t)m * NF + b];
+                    if (m < cfg->n_mel && b <= 200)
+                        host[f->fft_mel_off + (((size_t)(groups_total + e) / 4 * 64) + lane) * 4 + (e & 3)] = f->basis[(size_t)m * NF + b];
                 }
             groups_total += stored;
         }
