@@ -94,15 +94,28 @@ def secondary_lines(device):
     out = {}
     B, T = 4096, 300
     valu_pk_i16_peak = 256 * 64 * 2.4e9 * (8.0 / 3.0) / 1e12          # exact maddubs emulation: 8 int ops per 3 lane-instructions
+    # max|dlogit| and token agreement of the reduced-precision variants against the fp32 path on the
+    # same random-init weights and mel (64 streams x 300 frames)
+    acc_mel = (torch.randn(64, T, 40, device=device).abs() * 2).contiguous()
+    cfg32 = get_config()
+    m32 = DeployModel(cfg32, weights.init_weights(cfg32, seed=0), device=device)
+    ref = m32.forward(acc_mel, m32.zero_state(64), prev_word=m32.fresh_prev_word(64))
+    m32.close()
     for prec, steps in (("bf16", 5), ("int8", 3)):
         cfg = get_config(precision=prec)
         m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+        got = m.forward(acc_mel, m.zero_state(64), prev_word=m.fresh_prev_word(64))
+        dl = (got["logits"] - ref["logits"]).abs()
+        accuracy = {"vs": "fp32 path, same weights and mel, 64 streams x %d frames" % T,
+                    "max_abs_dlogit": float(dl.max()), "mean_abs_dlogit": float(dl.mean()),
+                    "frames_with_identical_decode2_token": float((got["tokens"] == ref["tokens"]).float().mean()),
+                    "streams_with_identical_token_sequence": float((got["tokens"] == ref["tokens"]).all(1).float().mean())}
         mel = (torch.randn(B, T, cfg.n_mel, device=device).abs() * 2).contiguous()
         st, pw = m.zero_state(B), m.fresh_prev_word(B)
         m.set_profiling(True)
         dt = timed(lambda: m.forward(mel, st, prev_word=pw, state_out=st), steps)
         kt = m.kernel_times()
-        entry = {"mel_frames_per_s": B * T / dt, "ms_per_step": dt * 1e3}
+        entry = {"mel_frames_per_s": B * T / dt, "ms_per_step": dt * 1e3, "accuracy": accuracy}
         if prec == "bf16":
             ms = kt[0][0] / max(kt[0][1], 1)
             tf = FLOP_PER_FRAME["total"] * B * T / (ms * 1e-3) / 1e12
