@@ -32,10 +32,14 @@ gru_layer_resident(const GruLayerParams p) {
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, g = lane >> 4, s = lane & 15;
-    const int group = blockIdx.x;
-    const int b_raw = group * kStreamsPerGroup + s;
-    const bool bvalid = b_raw < p.B;
-    const int b = bvalid ? b_raw : p.B - 1;
+    // Persistent over stream groups: the weights are staged ONCE per workgroup and launch; with more groups than the grid
+    // (B > 16 x CUs) a workgroup takes groups blockIdx.x, blockIdx.x + gridDim.x, ... one after the other.  Everything
+    // that depends on the group is (re)set at the top of the group loop below; the lambdas see it by reference.
+    const int n_groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
+    int group = blockIdx.x;
+    int b_raw = group * kStreamsPerGroup + s;
+    bool bvalid = b_raw < p.B;
+    int b = bvalid ? b_raw : p.B - 1;
     const int T = p.T;
     const int n0 = 2 * w, n1 = 2 * w + 1;
 
@@ -134,22 +138,40 @@ gru_layer_resident(const GruLayerParams p) {
         if (w == 0) bfc4 = ld4(p.bfc + 4 * g);
     }
 
-    // ---- initial state ---------------------------------------------------------------------------
-    const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
-    const int len_s = p.seq_len ? p.seq_len[b] - p.t_base : T;
+    // ---- per-group state: set by enter_group() -----------------------------------------------------
+    int len_s = T;
     f32x4 hreg[2];
+    const float4* xl_src = nullptr;
+    const float4* xprev = nullptr;
+    // the x-stream descriptors below (xl_row, xl_q, xl_active) do not depend on the group
+    constexpr int XQ = KCX;                          // float4 pieces per mel row (I == 4*KCX)
+    const int xl_row = lane / XQ, xl_q = lane % XQ;  // this lane's (stream-in-quarter, piece)
+    const bool xl_active = FIRST && lane < 4 * XQ;
+    auto enter_group = [&]() {
+        b_raw = group * kStreamsPerGroup + s;
+        bvalid = b_raw < p.B;
+        b = bvalid ? b_raw : p.B - 1;
+        const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
+        len_s = p.seq_len ? p.seq_len[b] - p.t_base : T;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = 2 * w + j;
-        hreg[j] = do_reset ? splat4(0.f) : ld4(p.state_in + (size_t)b * H + n * 16 + 4 * g);
-        hbuf[n * 64 + lane] = hreg[j];
-    }
-    if (LAST && tid < 16) {
-        const int bb = group * kStreamsPerGroup + tid;
-        int pw = -1;
-        if (bb < p.B && p.prev_word && !(p.reset && p.reset[bb])) pw = p.prev_word[bb];
-        epi.carry[tid] = pw;          // block 0 reads carry[0][.]
-    }
+        for (int j = 0; j < 2; ++j) {
+            const int n = 2 * w + j;
+            hreg[j] = do_reset ? splat4(0.f) : ld4(p.state_in + (size_t)b * H + n * 16 + 4 * g);
+            hbuf[n * 64 + lane] = hreg[j];
+        }
+        if (LAST && tid < 16) {
+            const int bb = group * kStreamsPerGroup + tid;
+            int pw = -1;
+            if (bb < p.B && p.prev_word && !(p.reset && p.reset[bb])) pw = p.prev_word[bb];
+            epi.carry[tid] = pw;          // block 0 reads carry[0][.]
+        }
+        if constexpr (FIRST) {
+            const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
+            xl_src = reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * (p.t_stride ? p.t_stride : T) * p.I) + xl_q;
+        } else {
+            xprev = p.x_prev + (size_t)group * T * NT * 64 + lane;
+        }
+    };
 
     // ---- x stream --------------------------------------------------------------------------------
     // First layer: the four waves fetch the group's mel frame COOPERATIVELY -- wave w loads streams
@@ -159,11 +181,6 @@ gru_layer_resident(const GruLayerParams p) {
     // dword loads per wave per frame were 4.5 % of this kernel.
     // Upper layers: the previous layer's xl-layout block, one slice per MFMA group (a burst of loads from
     // four phase-locked waves backs up the address path and stalls the MFMAs queued behind it).
-    constexpr int XQ = KCX;                          // float4 pieces per mel row (I == 4*KCX)
-    const int xl_row = lane / XQ, xl_q = lane % XQ;  // this lane's (stream-in-quarter, piece)
-    const bool xl_active = FIRST && lane < 4 * XQ;
-    const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
-    const float4* xl_src = FIRST ? reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * (p.t_stride ? p.t_stride : T) * p.I) + xl_q : nullptr;
     float4 xl_inflight = make_float4(0.f, 0.f, 0.f, 0.f);
     auto coop_issue = [&](int t_req) {               // global -> register (in flight)
         const int t = t_req < T ? t_req : T - 1;
@@ -178,7 +195,6 @@ gru_layer_resident(const GruLayerParams p) {
             dst[3 * kXsStride] = xl_inflight.w;
         }
     };
-    const float4* xprev = FIRST ? nullptr : p.x_prev + (size_t)group * T * NT * 64 + lane;
     float xbuf0[KCX];
     auto read_xs = [&](float (&dst)[KCX]) {          // xs -> this lane's B operands
         const float* row = xs + (4 * s + g) * kXsStride;
@@ -237,7 +253,6 @@ gru_layer_resident(const GruLayerParams p) {
         }
     };
 
-    __syncthreads();
     f32x4 hb_a, hb_b;            // exchange-read pipeline registers (two float4 in flight)
 
     // One frame (xcur == xnxt == the single B-operand buffer: x(t+1) lands in it during this frame).
@@ -379,6 +394,9 @@ gru_layer_resident(const GruLayerParams p) {
         }
     };
 
+    for (; group < n_groups; group += gridDim.x) {
+    enter_group();
+    __syncthreads();             // staged weights (first group) / this group's state and carry are in LDS
     if (T > 0) {
         if constexpr (FIRST) {
             coop_issue(0);
@@ -409,7 +427,8 @@ gru_layer_resident(const GruLayerParams p) {
         for (int j = 0; j < 2; ++j)
             *reinterpret_cast<f32x4*>(p.state_out + (size_t)b * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
     }
-    if (LAST && T == 0 && tid < 16) { /* nothing to flush; prev_word unchanged */ }
+    __syncthreads();             // every wave is done with this group's LDS state before the next group overwrites it
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,9 +790,35 @@ static hipError_t launch_with_lds(K kernel, const GruLayerParams& p, size_t lds,
     return hipGetLastError();
 }
 
+// the resident kernels loop over stream groups themselves: one workgroup per CU at most (each fills a CU's register file),
+// the weights staged once per workgroup however many groups it takes
+static int device_cu_count() {
+    static std::atomic<int> cached[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+template <typename K>
+static hipError_t launch_resident(K kernel, const GruLayerParams& p, size_t lds, hipStream_t st) {
+    static LdsGrant granted;
+    {
+        const hipError_t e = grant_dynamic_lds(kernel, granted, lds);
+        if (e != hipSuccess) return e;
+    }
+    const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup, cus = device_cu_count();
+    hipLaunchKernelGGL(kernel, dim3(groups < cus ? groups : cus), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool last, hipStream_t st) {
     const size_t lds = resident_lds_bytes(p.KCX, first, last);
-#define KWS_RES(KCX_, F_, L_) return launch_with_lds(gru_layer_resident<KCX_, F_, L_>, p, lds, st)
+#define KWS_RES(KCX_, F_, L_) return launch_resident(gru_layer_resident<KCX_, F_, L_>, p, lds, st)
     if (first) {
         if (p.KCX == 8) { if (last) KWS_RES(8, true, true); else KWS_RES(8, true, false); }
         if (p.KCX == 10) { if (last) KWS_RES(10, true, true); else KWS_RES(10, true, false); }
