@@ -452,10 +452,11 @@ gru_stack_bf16_ls(const GruBf16Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int layer = wave >> 2, w = wave & 3;             // w: this wave's 32 units within its layer
     const int lane = tid & 63, g = lane >> 4, s = lane & 15;
-    const int group = blockIdx.x;
-    const int b_raw = group * kStreamsPerGroup + s;
-    const bool bvalid = b_raw < p.B;
-    const int b = bvalid ? b_raw : p.B - 1;
+    // persistent over stream groups (as the fp32 resident kernels): operands and LDS tables are set up once per workgroup
+    const int n_groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
+    int group = blockIdx.x;
+    int b_raw = 0, b = 0;
+    bool bvalid = false;
     const int T = p.T;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -474,20 +475,34 @@ gru_stack_bf16_ls(const GruBf16Params p) {
         const int ln = i & 63, c = (i >> 6) & 7, j = (i >> 9) & 1, ww = i >> 10;
         wc1[i] = reinterpret_cast<const u32x4*>(p.w[1])[(((2 * ww + j) * 3 + 2) * KC1 + c) * 64 + ln];
     }
-    const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
-    const int len_s = p.seq_len ? p.seq_len[b] : T;
+    int len_s = T;
     f32x4 hreg[2];
+    auto enter_group = [&]() {
+        b_raw = group * kStreamsPerGroup + s;
+        bvalid = b_raw < p.B;
+        b = bvalid ? b_raw : p.B - 1;
+        const bool do_reset = p.reset != nullptr && p.reset[b] != 0;
+        len_s = p.seq_len ? p.seq_len[b] : T;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-        hreg[j] = do_reset ? splat4(0.f) : ld4(p.state_in + ((size_t)layer * p.B + b) * H + (2 * w + j) * 16 + 4 * g);
-    hb[(layer * 4 + w) * 64 + lane] = (u32x4){pack_bf16(hreg[0][0], hreg[0][1]), pack_bf16(hreg[0][2], hreg[0][3]),
-                                               pack_bf16(hreg[1][0], hreg[1][1]), pack_bf16(hreg[1][2], hreg[1][3])};
-    if (tid < 16) {
-        const int bb = group * kStreamsPerGroup + tid;
-        int pw = -1;
-        if (bb < p.B && p.epi.prev_word && !(p.reset && p.reset[bb])) pw = p.epi.prev_word[bb];
-        epi.carry[tid] = pw;
-    }
+        for (int j = 0; j < 2; ++j)
+            hreg[j] = do_reset ? splat4(0.f) : ld4(p.state_in + ((size_t)layer * p.B + b) * H + (2 * w + j) * 16 + 4 * g);
+        hb[(layer * 4 + w) * 64 + lane] = (u32x4){pack_bf16(hreg[0][0], hreg[0][1]), pack_bf16(hreg[0][2], hreg[0][3]),
+                                                   pack_bf16(hreg[1][0], hreg[1][1]), pack_bf16(hreg[1][2], hreg[1][3])};
+        if (tid < 16) {
+            const int bb = group * kStreamsPerGroup + tid;
+            int pw = -1;
+            if (bb < p.B && p.epi.prev_word && !(p.reset && p.reset[bb])) pw = p.epi.prev_word[bb];
+            epi.carry[tid] = pw;
+        }
+    };
+    auto leave_group = [&]() {
+        if (bvalid) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<f32x4*>(p.state_out + ((size_t)layer * p.B + b) * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
+        }
+        __syncthreads();         // every wave is done with this group's LDS state before the next group's is written
+    };
     const f32x4* bl = reinterpret_cast<const f32x4*>(biasl + layer * 3 * H);
     // the epilogue's barriers are workgroup barriers: layer 0's waves keep step with them
     auto flush_due = [&](int i) { return i >= 0 && ((((i + 1) & (kRingFrames - 1)) == 0) || i == T - 1); };
@@ -509,8 +524,7 @@ gru_stack_bf16_ls(const GruBf16Params p) {
         const int XQ = p.I / 4;
         const int xl_row = lane / XQ, xl_q = lane % XQ;
         const bool xl_active = lane < 4 * XQ;
-        const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
-        const float4* xl_src = reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * T * p.I) + xl_q;
+        const float4* xl_src = nullptr;
         unsigned* xs_dst = reinterpret_cast<unsigned*>(xsb) +
                            (((xl_q * 4) / 32) * 64 + (((xl_q * 4) % 32) / 8) * 16 + (4 * w + xl_row)) * 4 + ((xl_q * 4) % 8) / 2;
         float4 fl_a = make_float4(0.f, 0.f, 0.f, 0.f), fl_b = fl_a;
@@ -518,14 +532,6 @@ gru_stack_bf16_ls(const GruBf16Params p) {
         auto commit = [&](const float4& r) {
             if (xl_active) *reinterpret_cast<uint2*>(xs_dst) = make_uint2(pack_bf16(r.x, r.y), pack_bf16(r.z, r.w));
         };
-        __syncthreads();
-        if (T > 0) {
-            fetch(fl_a, 0);
-            commit(fl_a);                 // x(0)
-            fetch(fl_b, 1);
-            fetch(fl_a, 2);
-        }
-        __syncthreads();
         auto iteration = [&](int i, float4& fl_commit) {
             bf16x8 xB[KX0], h0B[4];
 #pragma unroll
@@ -608,9 +614,25 @@ gru_stack_bf16_ls(const GruBf16Params p) {
                 epilogue_flush(p.epi, epi, group, t0, i - t0 + 1, w, lane, i == T - 1);
             }
         };
-        for (int i = -1; i < T; i += 2) {
-            iteration(i, fl_b);
-            if (i + 1 < T) iteration(i + 1, fl_a);
+        for (; group < n_groups; group += gridDim.x) {
+            enter_group();
+            {
+                const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
+                xl_src = reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * T * p.I) + xl_q;
+            }
+            __syncthreads();
+            if (T > 0) {
+                fetch(fl_a, 0);
+                commit(fl_a);                 // x(0)
+                fetch(fl_b, 1);
+                fetch(fl_a, 2);
+            }
+            __syncthreads();
+            for (int i = -1; i < T; i += 2) {
+                iteration(i, fl_b);
+                if (i + 1 < T) iteration(i + 1, fl_a);
+            }
+            leave_group();
         }
     } else {
         // ================= layer 1: frame i in iteration i, the dense layer and the epilogue =================
@@ -629,8 +651,6 @@ gru_stack_bf16_ls(const GruBf16Params p) {
         f32x4 bfc4 = splat4(0.f);
         if (w == 0) bfc4 = ld4(p.bfc + 4 * g);
         const u32x4* wcl = wc1 + (size_t)w * 2 * 8 * 64 + lane;      // [tile][chunk][64]
-        __syncthreads();
-        __syncthreads();
         auto iteration = [&](int i) {
             bf16x8 h0B[4], h1B[4];
 #pragma unroll
@@ -713,12 +733,13 @@ gru_stack_bf16_ls(const GruBf16Params p) {
             lds_barrier();            // #2
             if (flush_due(i)) { lds_barrier(); lds_barrier(); }     // the fold and the flush by layer 0's waves
         };
-        for (int i = -1; i < T; ++i) iteration(i);
-    }
-    if (bvalid) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            *reinterpret_cast<f32x4*>(p.state_out + ((size_t)layer * p.B + b) * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
+        for (; group < n_groups; group += gridDim.x) {
+            enter_group();
+            __syncthreads();
+            __syncthreads();
+            for (int i = -1; i < T; ++i) iteration(i);
+            leave_group();
+        }
     }
 }
 
@@ -756,7 +777,17 @@ static hipError_t launch_bf16_ls(const GruBf16Params& p, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
-    hipLaunchKernelGGL((gru_stack_bf16_ls<KX0>), dim3(groups), dim3(512), lds, st, p);
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    static std::atomic<int> cu_cache[kMaxDevices];
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) {
+        cus = cu_cache[dev].load(std::memory_order_relaxed);
+        if (cus <= 0) {
+            cus = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            cu_cache[dev].store(cus, std::memory_order_relaxed);
+        }
+    }
+    hipLaunchKernelGGL((gru_stack_bf16_ls<KX0>), dim3(groups < cus ? groups : cus), dim3(512), lds, st, p);
     return hipGetLastError();
 }
 
