@@ -147,3 +147,34 @@ def test_reserved_scratch_is_never_regrown_and_layouts_can_alternate():
     m.kernel_times()
     one = ref.forward(mel[:, :100].contiguous(), ref.zero_state(b))
     assert torch.equal(r["logits"], one["logits"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_more_stream_groups_than_cus_persistent_workgroups(precision):
+    """B = 8200 streams = 513 groups of 16 (the last one ragged) on 256 CUs: the resident / bf16 kernels stage their weights once
+    per workgroup and walk groups blockIdx, blockIdx + 256, ...  A stream's result must not depend on which workgroup, in
+    which of its rounds, computed it: sampled streams of the first, a middle and the last round -- group seams and the
+    ragged tail included -- equal, bit for bit, the same streams run as a small batch; state, reset mask, sequence lengths
+    and the ctc_decode2 carry (prev_word) go through the per-group re-entry too; and a second call continues correctly."""
+    w = G.init_weights()
+    b, t = 8200, 23
+    mel = _mel(b, 2 * t, 40, 181)
+    m = _model(precision=precision, weights=w)
+    gen = torch.Generator(device="cpu").manual_seed(182)
+    state = (0.2 * torch.randn(2, b, 128, generator=gen)).cuda()
+    reset = (torch.rand(b, generator=gen) < 0.1).to(torch.uint8).cuda()
+    seq = torch.randint(1, t + 1, (b,), generator=gen, dtype=torch.int32).cuda()
+    pw = m.fresh_prev_word(b)
+    r1 = m.forward(mel[:, :t].contiguous(), state, seq_len=seq, reset_mask=reset, prev_word=pw)
+    r2 = m.forward(mel[:, t:].contiguous(), r1["state"], prev_word=pw)
+    pick = [0, 15, 16, 4079, 4080, 4095, 4096, 4097, 4111, 4112, 6000, 8175, 8176, 8191, 8192, 8199]
+    idx = torch.tensor(pick).cuda()
+    pws = m.fresh_prev_word(len(pick))
+    s1 = m.forward(mel[idx, :t].contiguous(), state[:, idx].contiguous(), seq_len=seq[idx].contiguous(),
+                   reset_mask=reset[idx].contiguous(), prev_word=pws)
+    s2 = m.forward(mel[idx, t:].contiguous(), s1["state"], prev_word=pws)
+    for big, small in ((r1, s1), (r2, s2)):
+        assert torch.equal(big["logits"][idx], small["logits"]) and torch.equal(big["softmax"][idx], small["softmax"])
+        assert torch.equal(big["state"][:, idx], small["state"]) and torch.equal(big["tokens"][idx], small["tokens"])
+    assert torch.equal(pw[idx], pws)
+    assert bool(torch.isfinite(r2["logits"]).all())
