@@ -176,6 +176,11 @@ def secondary_lines(device):
                                      "tflops": FLOP_PER_FRAME["layer"][l] * frames / (per[l] * 1e-3) / 1e12,
                                      "frac": FLOP_PER_FRAME["layer"][l] * frames / (per[l] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
                                     for l in range(len(per))]
+            for l, pat in enumerate(("gru_layer_resident<10, true, false>", "gru_layer_resident<32, false, true>")):
+                rp, rp_src = rocprof_kernel_avg_ms(pat, "e2e")           # the committed trace of tools/bench_e2e.py (same loop)
+                if rp:
+                    entry["gru_kernels"][l].update({"kernel_ms_rocprof": rp, "rocprof_source": rp_src,
+                                                    "frac_rocprof": FLOP_PER_FRAME["layer"][l] * frames / (rp * 1e-3) / 1e12 / PEAK_FP32_TFLOPS})
             # the front-end kernel alone on one chunk with its carried samples (22 frames per stream): HBM-bound,
             # algorithmic bytes = PCM in (3840 samples) + mel out
             carry = torch.zeros(B, 240, device=device)
