@@ -146,6 +146,20 @@ class HotwordDetector(object):
         mel = frontend.forward(data.contiguous())
         return self.feed(mel, pcm_chunk=chunk)
 
+    def test(self, pcm, frontend, label=None):
+        """detector.py:214-229 without the file and plot I/O: whole utterances [B,N] (or [N]) of PCM in ONE run from the
+        detector's current state -- front-end, GRU stack -- then ctc_decode over the whole softmax and ctc_predict.
+        Returns (hit [B] int32, (words, counts), softmax [B,T,C], logits [B,T,C]); the state is left untouched, as there."""
+        x = torch.as_tensor(pcm)
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        x = buf_to_float(x.to(self.model.device))
+        mel = frontend.forward(x.contiguous())
+        state = self.state if x.shape[0] == self.batch else self.model.zero_state(int(x.shape[0]))
+        r = self.model.forward(mel, state, want_logits=True, want_softmax=True)
+        decoded = decode_batch(_lib.DECODE, r["softmax"], None, 3, 0.5, 0.2)                     # :224
+        return _ctc_predict(decoded, label or self.label), decoded, r["softmax"], r["logits"]    # :226
+
     def test2(self, mel, chunk_frames):
         """detector.py:254-289: replay whole utterances [B,T,n_mel] in chunks with the state threaded
         through, accumulate the softmax, decode once with ctc_decode.  Returns (words, counts)."""

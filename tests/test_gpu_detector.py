@@ -271,3 +271,36 @@ def test_stream_manager_takes_kws_vad_s_decision_on_borderline_chunks():
     zeroed.feed_pcm(edge, fe)
     same = (kept.state == zeroed.state).all(0).all(1).cpu().numpy()
     np.testing.assert_array_equal(same, ~want_speech.bool().cpu().numpy())
+
+
+def test_one_shot_test_equals_the_chunked_replay_and_the_oracle():
+    """detector.py:214-229 (`test`: one sess.run over the whole utterance, ctc_decode, ctc_predict) next to :254-289
+    (`test2`: the same utterance in chunks with the state threaded through): same softmax bits, same words; and the words
+    are what the oracle's ctc_decode makes of the oracle's softmax wherever no frame sits at a decision edge."""
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.detector import HotwordDetector
+    from keyword_spotting_amd.frontend import MelFrontend
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    from oracle import frontend_oracle as F
+    cfg = get_config()
+    w = G.init_weights(seed=4)
+    w["Wfc"] = (w["Wfc"] * 3).astype(np.float32)
+    fe = MelFrontend(cfg)
+    det = HotwordDetector(DeployModel(cfg, w), batch=3, label="12")
+    rng = np.random.default_rng(123)
+    pcm = (rng.standard_normal((3, 16000)) * 0.2).astype(np.float32)
+    hit, (words, counts), softmax, logits = det.test(pcm, fe)
+    assert softmax.shape == (3, D.frames_in(16000), 6) and logits.shape == softmax.shape and not det.state.any()
+    mel = fe.forward(torch.from_numpy(pcm))
+    words2, counts2 = det.test2(mel, [22, 23] * 2 + [int(mel.shape[1]) - 90])
+    assert torch.equal(words, words2) and torch.equal(counts, counts2)
+    want_mel = F.melspec(pcm).astype(np.float32)
+    for s in range(3):
+        lg, _ = G.gru_forward(w, want_mel[s:s + 1], dtype=np.float64)
+        sm = G.softmax(lg)[0]
+        assert np.abs(softmax[s].cpu().numpy() - sm).max() < 5e-5
+        p = np.sort(sm[:, 1:5], axis=1)
+        if min(np.abs(p[:, -1] - t).min() for t in (0.5, 0.2, 0.6)) > 1e-3 and (p[:, -1] - p[:, -2]).min() > 1e-3 and np.abs(sm[:, 3] - 0.2).min() > 1e-3:
+            got = words[s, :int(counts[s])].cpu().numpy()
+            np.testing.assert_array_equal(got, D.ctc_decode(sm)[1::2])
+            assert int(hit[s]) == D.ctc_predict(D.ctc_decode(sm), "12")
