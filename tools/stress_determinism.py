@@ -67,4 +67,6 @@ tot += repeat("bf16 stack", get_config(precision="bf16"), 4096, 100, n)
 tot += repeat("fp32 resident", get_config(), 4096, 100, n)
 tot += repeat("fp32 resident, layers overlapped on streams", get_config(), 1024, 200, n)
 tot += repeat("fp32 resident 4 layers, overlapped", get_config(num_layers=4), 1024, 130, n)
+tot += repeat("fp32 resident, persistent over 513 groups", get_config(), 8200, 30, n)
+tot += repeat("bf16 stack, persistent over 513 groups", get_config(precision="bf16"), 8200, 30, n)
 sys.exit(1 if tot else 0)
