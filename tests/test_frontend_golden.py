@@ -1,0 +1,84 @@
+"""Front-end (models/rnn_ctc.py:134-149) against a third-party fixture: tests/golden/frontend_golden.npz, written by
+tests/golden/make_frontend_golden.py from `transformers.audio_utils` (Slaney/Slaney mel bank = librosa.filters.mel's
+default; rectangular 400/160 un-centred magnitude spectrogram).  Not the reference itself -- the stage stays "parity
+partial" -- but neither the oracle's nor the kernel's author wrote it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend_oracle as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "frontend_golden.npz"))
+CASES = sorted(k[4:] for k in GOLD.files if k.startswith("pcm_"))
+REL_TOL = 2e-5          # of the largest mel value of the case (fp32 FFT + fp32 mel matmul); same as test_gpu_frontend.py
+
+
+def test_fixture_covers_what_it_should():
+    assert len(CASES) == 7 and GOLD["basis_40"].shape == (201, 40) and GOLD["basis_60"].shape == (201, 60)
+    assert GOLD["mel40_noise_3600"].shape == (21, 40)          # detector.py's first chunk: 21 frames
+    assert GOLD["mel40_noise_loud_3840"].shape == (22, 40)     # 3600 + 240 carried samples: 22 frames
+
+
+@pytest.mark.parametrize("n_mel", [40, 60])
+def test_oracle_mel_basis_is_the_slaney_bank(n_mel):
+    want = GOLD["basis_%d" % n_mel]                            # [201, n_mel] = librosa's [n_mel, 201] transposed
+    np.testing.assert_allclose(F.mel_basis(16000, 400, n_mel, 300.0, 8000.0).T, want, atol=1e-15)
+
+
+@pytest.mark.parametrize("n_mel", [40, 60])
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_melspec_matches_third_party_spectrogram(name, n_mel):
+    want = GOLD["mel%d_%s" % (n_mel, name)]
+    got = F.melspec(GOLD["pcm_" + name][None], n_mels=n_mel)[0]
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-7 * max(np.abs(want).max(), 1.0)
+
+
+# --------------------------------------------------------------------------------------------- GPU, through the C ABI
+def _frontend(n_mel):
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.frontend import MelFrontend
+    return MelFrontend(get_config(n_mel=n_mel))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mel", [40, 60])
+def test_kws_frontend_mel_basis_is_the_slaney_bank(n_mel):
+    got = _frontend(n_mel).mel_basis()                         # [n_mel, 201] fp32
+    np.testing.assert_allclose(got.T, GOLD["basis_%d" % n_mel], rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mel", [40, 60])
+@pytest.mark.parametrize("name", CASES)
+def test_kws_frontend_run_matches_third_party_spectrogram(name, n_mel):
+    fe = _frontend(n_mel)
+    pcm = GOLD["pcm_" + name]
+    want = GOLD["mel%d_%s" % (n_mel, name)]
+    got = fe.forward(torch.from_numpy(pcm.copy())).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < REL_TOL * np.abs(want).max()
+    # and as one stream among many (the batched kernel takes a different tile path for >= 16 streams)
+    many = np.tile(pcm, (33, 1))
+    got_b = fe.forward(torch.from_numpy(many)).cpu().numpy()
+    assert np.array_equal(got_b[0], got) and np.array_equal(got_b[32], got)
+
+
+@pytest.mark.gpu
+def test_session_run_on_pcm_produces_the_fixture_mel_before_the_gru():
+    """DeployModel.run's PCM feed goes through the same front-end (models/rnn_ctc.py:130-149)."""
+    from keyword_spotting_amd import get_config, weights
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    from oracle import gru_oracle as G
+    cfg = get_config()
+    w = weights.init_weights(cfg, seed=0)
+    m = DeployModel(cfg, w)
+    pcm = GOLD["pcm_noise_loud_3840"]
+    sm, st = m.run(["model/softmax:0", "model/rnn_states:0"],
+                   {"model/inputX:0": pcm, "model/rnn_initial_states:0": np.zeros((2, 1, 128), np.float32)})
+    want_l, want_s = G.gru_forward(w, GOLD["mel40_noise_loud_3840"][None].astype(np.float32), dtype=np.float64)
+    assert np.abs(torch.as_tensor(sm).cpu().numpy().reshape(22, 6) - G.softmax(want_l)[0]).max() < 2e-5
+    assert np.abs(torch.as_tensor(st).cpu().numpy() - want_s).max() < 1e-4
