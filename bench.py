@@ -27,6 +27,35 @@ PEAK_FP32_TFLOPS = 157.3                                                      # 
 PEAK_HBM_GBS = 8000.0
 
 
+def csrc_hash():
+    """sha1 over the kernel sources this build was made from; tools/prof.sh stores it next to every profile set
+    (profiles/<tag>_source_hash.txt) so that figures read back from a committed profile are dropped when the kernels
+    have changed since."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "keyword_spotting_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_is_current(path):
+    """True iff the profile file `path` (relative to the repo root) was taken from the kernel sources of this build."""
+    if not path:
+        return False
+    import re
+    m = re.match(r"^(r\d+(?:_[A-Za-z0-9]+?)?)_(?:kernel_stats\.csv|pmc\.json)$", os.path.basename(path))
+    if not m:
+        return False
+    stamp = os.path.join(ROOT, "profiles", m.group(1) + "_source_hash.txt")
+    try:
+        return open(stamp).read().split()[0] == csrc_hash()
+    except Exception:
+        return False
+
+
 def rocprof_kernel_avg_ms(pattern, tag=None):
     """Average duration (ms) of the first kernel whose name contains `pattern` in the latest committed
     profiles/r<round>[_<tag>]_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command), and the file."""
@@ -38,6 +67,8 @@ def rocprof_kernel_avg_ms(pattern, tag=None):
     if not files:
         return None, None
     latest = max(files, key=lambda f: int(rx.match(os.path.basename(f)).group(1)))
+    if not profile_is_current(latest):              # kernels changed since that trace: do not quote it
+        return None, os.path.relpath(latest, ROOT) + " (stale: taken from other kernel sources)"
     for row in csv.DictReader(open(latest)):
         if pattern in row.get("Name", ""):
             return float(row["AverageNs"]) * 1e-6, os.path.relpath(latest, ROOT)
@@ -53,6 +84,8 @@ def pmc_bytes(pattern, tag):
     if not files:
         return None, None
     latest = max(files, key=lambda f: int(rx.match(os.path.basename(f)).group(1)))
+    if not profile_is_current(latest):
+        return None, os.path.relpath(latest, ROOT) + " (stale: taken from other kernel sources)"
     for k, c in json.load(open(latest)).items():
         if pattern in k and "hbm_bytes_per_launch" in c:
             return c["hbm_bytes_per_launch"], os.path.relpath(latest, ROOT)
@@ -119,7 +152,7 @@ def secondary_lines(device):
         if prec == "bf16":
             ms = kt[0][0] / max(kt[0][1], 1)
             tf = FLOP_PER_FRAME["total"] * B * T / (ms * 1e-3) / 1e12
-            entry["roofline"] = {"bound": "mfma", "kernel": "gru_stack_bf16 (both layers fused)", "kernel_ms": ms, "achieved": tf,
+            entry["roofline"] = {"bound": "mfma", "kernel": m.kernel_names()[0], "kernel_ms": ms, "achieved": tf,
                                  "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
                                  "hbm_algorithmic_GBps": BYTES_PER_FRAME * B * T / (ms * 1e-3) / 1e9}
         else:
@@ -196,7 +229,7 @@ def secondary_lines(device):
                                               "kernel_ms_rocprof": rp_ms, "rocprof_source": rp_src}}
         else:
             ms = kt[0][0] / max(kt[0][1], 1)
-            entry["gru_kernels"] = [{"kernel": "gru_stack_bf16", "kernel_ms": ms,
+            entry["gru_kernels"] = [{"kernel": m.kernel_names()[0], "kernel_ms": ms,
                                      "tflops": FLOP_PER_FRAME["total"] * frames / (ms * 1e-3) / 1e12,
                                      "frac": FLOP_PER_FRAME["total"] * frames / (ms * 1e-3) / 1e12 / 2500.0}]
         out["detector.py loop, PCM in -> trigger out, %s, %d streams x 225 ms chunks (VAD, front-end, GRU, window)" % (prec, B)] = entry
@@ -291,6 +324,22 @@ def cpu_baseline(cfg, w, seconds_budget=25.0):
             state = torch.from_numpy(state.numpy().copy())
             frames += lg.shape[1]
     eager = frames / (time.perf_counter() - t0)
+    # ... and on all usable cores at once, one independent batch-1 stream per pinned process (BASELINE.md section 3 asks
+    # for each arm on 1 and on N cores): fresh interpreters (spawn), so nothing of this process's GPU state is inherited
+    eager_all, eager_all_note = None, None
+    if cores > 1:
+        try:
+            import multiprocessing as mp
+            cpus = sorted(os.sched_getaffinity(0))
+            pin = [cpus[i * len(cpus) // cores] for i in range(cores)] if len(cpus) >= cores else [None] * cores   # spread over the mask
+            with mp.get_context("spawn").Pool(cores) as pool:
+                rates = pool.map(TE.eager_stream_rate, [(c, seconds_budget / 5, cfg.n_mel, cfg.hidden_size, cfg.num_layers,
+                                                        cfg.num_classes) for c in pin])
+            eager_all = float(sum(rates))
+            eager_all_note = "%d pinned single-thread processes, one stream each, ~%.0fs: min %.0f / max %.0f frames/s per process" % (
+                cores, seconds_budget / 5, min(rates), max(rates))
+        except Exception as exc:              # never lose the line over the baseline's baseline
+            eager_all_note = "not measured: %r" % (exc,)
     return {"value": call, "unit": "mel-frames/s", "cores": cores, "kind": "port",
             "sample": "oracle/kws_oracle.c (restatement of reference semantics; TF-1.x not executable): "
                       "%d independent batch-1 streams x 300 frames + ctc_decode2 per pass, OpenMP team of %d "
@@ -298,7 +347,28 @@ def cpu_baseline(cfg, w, seconds_budget=25.0):
                       % (cores * 8, cores, quota, visible, seconds_budget * 0.4),
             "single_core_value": c1,
             "eager_stand_in": {"value": eager, "cores": 1, "what": "torch-CPU op-by-op GRUCell loop, batch 1, 22-frame "
-                               "chunks, state round trip (analogue of the reference's per-op TF dispatch)"}}
+                               "chunks, state round trip (analogue of the reference's per-op TF dispatch)",
+                               "all_cores_value": eager_all, "all_cores": cores, "all_cores_how": eager_all_note,
+                               "extrapolated_x_cores": eager * cores}}
+
+
+def sustained_run(step, device_sync, frames_per_step, seconds, window=100):
+    """Runs `step` back to back for at least `seconds`, synchronising every `window` steps: mean mel-frames/s over the
+    whole run, the slowest/fastest window, and last-window / first-window (clock droop under sustained load shows here)."""
+    rates = []
+    device_sync()
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < seconds or len(rates) < 2:
+        t0 = time.perf_counter()
+        for _ in range(window):
+            step()
+        device_sync()
+        rates.append(window * frames_per_step / (time.perf_counter() - t0))
+    total = time.perf_counter() - t_start
+    return {"seconds": total, "steps": window * len(rates), "window_steps": window, "windows": len(rates),
+            "mel_frames_per_s": window * len(rates) * frames_per_step / total,
+            "min_window": min(rates), "max_window": max(rates), "first_window": rates[0], "last_window": rates[-1],
+            "last_over_first": rates[-1] / rates[0]}
 
 
 def pmc_traffic_all():
@@ -311,6 +381,8 @@ def pmc_traffic_all():
     if not files:
         return {}, None
     latest = max(files, key=lambda f: int(re.match(r"^r(\d+)_", os.path.basename(f)).group(1)))
+    if not profile_is_current(latest):
+        return {}, os.path.relpath(latest, ROOT) + " (stale: taken from other kernel sources)"
     data = json.load(open(latest))
     return {k: c["hbm_bytes_per_launch"] for k, c in data.items() if "hbm_bytes_per_launch" in c}, os.path.relpath(latest, ROOT)
 
@@ -328,7 +400,8 @@ def main(argv=None, model_factory=None):
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "int8"],
                     help="fp32 = the reference arithmetic (headline); bf16 / int8 = BASELINE configs[2] variants (secondary)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the sustained run, the secondary lines and the CPU baseline")
+    ap.add_argument("--sustain-seconds", type=float, default=10.0, help="length of the sustained-load run after the timed region")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the "
                     "multi-process path on a box with fewer GPUs than ranks")
     args = ap.parse_args(argv)
@@ -406,12 +479,16 @@ def main(argv=None, model_factory=None):
     for _ in range(args.steps):
         step()
     device_sync()
+    elapsed_own = time.perf_counter() - t0          # this rank alone (per_rank); `value` uses the barrier-to-barrier time
     sharding.barrier(dist, sync_device)
     elapsed = time.perf_counter() - t0
     ktimes = model.kernel_times(reset=True)
     model.set_profiling(False)
     frames, seconds = sharding.reduce_throughput(dist, B * T * args.steps, elapsed, sync_device)
     ranks_seen = sharding.count_ranks(dist, sync_device)
+    # who took part: host, device identity and own rate of every rank, so that an N-GPU line proves N distinct devices and
+    # shows the slowest one (8 bytes of bookkeeping per rank after the timed region; not a data-path collective)
+    per_rank = sharding.gather_rank_info(dist, sharding.rank_identity(rank, local_rank, device, B * T * args.steps / elapsed_own))
 
     if rank == 0:
         value = frames / seconds
@@ -450,6 +527,8 @@ def main(argv=None, model_factory=None):
                        "streams_per_gpu": B, "frames_per_step": T, "parallelism": "utterance-dp%d" % world,
                        "kernel": getattr(model, "kernel", "stub")},
             "realtime_streams": value / 100.0,
+            "per_rank": per_rank,
+            "distinct_devices": len({(r.get("host"), r.get("device_id")) for r in per_rank}),
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          # the same fraction from the committed rocprofv3 kernel-trace average of this command (tracer attached)
@@ -471,14 +550,19 @@ def main(argv=None, model_factory=None):
                          "hbm_frac_of_peak": BYTES_PER_FRAME * B * T / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
         if world == 1 and not args.no_cpu_baseline and not stub:
+            # the headline above is K steps (tens of milliseconds): the same step() for >= 10 s tells whether it holds under
+            # sustained power/thermal load (reported beside it, never as `value`)
+            line["sustained"] = sustained_run(step, device_sync, B * T, args.sustain_seconds)
             try:
                 line["secondary"] = secondary_lines(device)
             except Exception as exc:          # informational only: never lose the headline line over it
                 line["secondary"] = {"error": repr(exc)}
             line["cpu_baseline"] = cpu_baseline(cfg, w)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
-            line["speedup_vs_eager_stand_in_x_cores"] = value / (line["cpu_baseline"]["eager_stand_in"]["value"]
-                                                                 * line["cpu_baseline"]["cores"])
+            es = line["cpu_baseline"]["eager_stand_in"]
+            line["speedup_vs_eager_stand_in_x_cores"] = value / (es["value"] * line["cpu_baseline"]["cores"])
+            if es.get("all_cores_value"):
+                line["speedup_vs_eager_stand_in_all_cores_measured"] = value / es["all_cores_value"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -75,6 +75,8 @@ typedef struct kws_model* kws_handle;
 enum { KWS_KERNEL_AUTO = 0, KWS_KERNEL_GENERIC = 1, KWS_KERNEL_RESIDENT = 2 };
 enum { KWS_DECODE = 0, KWS_DECODE2 = 1, KWS_DECODE_STRICT = 2 };
 
+/* "kws_amd <ver> (gfx950; HIP x.y.z; <compiler version>; bf16 mfma-vgpr-form=<0|1>)": the compiler is part of the version
+ * because the kernels depend on hand-placed MFMA hazard fences and on an internal LLVM option (csrc/Makefile). */
 const char* kws_version(void);
 /* sizeof(kws_config) / sizeof(kws_frontend_config) as this library was compiled: a binding written in another
  * language (ctypes, cffi, JNI ...) compares it with its own struct declaration at load time, so a field added here
@@ -115,6 +117,18 @@ int kws_scratch_stats(kws_handle h, size_t* bytes_reserved, int32_t* allocations
  * validate a given step, synchronise its stream first.  The same condition is also reported by the next kws_step and
  * by kws_kernel_times, whichever comes first; reporting clears it.  (kws_destroy only leaves it in kws_last_error().) */
 int kws_poll_error(kws_handle h);
+
+/* Proves the kernels `h` would launch (its shape and precision; for fp32 both the register-resident and the generic
+ * family where the shape allows) against known answers the library carries itself: TensorFlow's published GRUCell /
+ * MultiRNNCell unit-test constants (0.175991, 0.156736, 0.13248) embedded in the handle's shape, and 19 streams x 8
+ * random frames against a plain double-precision host loop of the cell (models/rnn_ctc.py:179-185,228-243 semantics).
+ * Uses temporary handles and buffers, synchronises the device, a few milliseconds.  KWS_OK, or KWS_ERR_HIP with a
+ * message naming the kernel, the deviation and kws_version().  With KWS_SELFTEST=1 in the environment every
+ * kws_create runs it and fails the same way.  (There is still no CPU fallback: a failed self-test is an error.) */
+int kws_selftest(kws_handle h);
+/* Name of the kernel(s) the last kws_step of this handle launched for profiling slot `slot` (0..L-1; "" when that layer
+ * ran inside another slot's launch), e.g. "gru_layer_resident<32, false, true>".  buf: host memory of n bytes. */
+int kws_last_launch(kws_handle h, int slot, char* buf, size_t n);
 
 /* Advances B independent streams by T frames (one 10 ms hop each).
  *   mel        [B,T,I]  f32, 16-byte aligned         model/inputX:0 (mel variant), batch-major

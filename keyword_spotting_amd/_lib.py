@@ -56,6 +56,8 @@ _SIGNATURES = {
     "kws_reserve": (_i, [_vp, _i, _i]),
     "kws_scratch_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int32)]),
     "kws_poll_error": (_i, [_vp]),
+    "kws_selftest": (_i, [_vp]),
+    "kws_last_launch": (_i, [_vp, _i, ctypes.c_char_p, ctypes.c_size_t]),
     "kws_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "kws_set_profiling": (_i, [_vp, _i]),
     "kws_kernel_times": (_i, [_vp, _vp, _vp, _i]),

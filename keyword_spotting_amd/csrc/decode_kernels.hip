@@ -136,16 +136,21 @@ hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float t
     return hipGetLastError();
 }
 
-__global__ void state_passthrough_kernel(const float* __restrict__ state_in, float* __restrict__ state_out, const uint8_t* __restrict__ reset,
-                                         int L, int B, int H) {
+// state_in and state_out may be the same buffer (kws_stream_feed works in place): no __restrict__ on them
+__global__ void state_passthrough_kernel(const float* state_in, float* state_out, const uint8_t* __restrict__ reset,
+                                         int32_t* __restrict__ prev_word, int L, int B, int H) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)L * B * H) return;
     const int b = (int)((i / H) % B);
     state_out[i] = reset[b] ? 0.f : state_in[i];
+    // a reset stream starts its ctc_decode2 neighbour rule from pre_word = -1, exactly as the T > 0 kernels do
+    if (prev_word && reset[b] && i < (size_t)B * H && i % H == 0) prev_word[b] = -1;
 }
-hipError_t launch_state_passthrough(const float* state_in, float* state_out, const uint8_t* reset, int L, int B, int H, hipStream_t st) {
+hipError_t launch_state_passthrough(const float* state_in, float* state_out, const uint8_t* reset, int32_t* prev_word, int L, int B, int H,
+                                    hipStream_t st) {
     const size_t n = (size_t)L * B * H;
-    hipLaunchKernelGGL(state_passthrough_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, state_in, state_out, reset, L, B, H);
+    hipLaunchKernelGGL(state_passthrough_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, state_in, state_out, reset, prev_word,
+                       L, B, H);
     return hipGetLastError();
 }
 

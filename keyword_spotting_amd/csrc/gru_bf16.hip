@@ -791,9 +791,26 @@ static hipError_t launch_bf16_ls(const GruBf16Params& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st) {
-    // two layers: the layer-specialised 8-wave kernel (KWS_BF16_WAVES=4 keeps the 4-wave kernel for A/B)
+static bool bf16_four_waves() {
     static const bool four = [] { const char* e = getenv("KWS_BF16_WAVES"); return e && e[0] == '4'; }();
+    return four;
+}
+const char* gru_stack_bf16_kernel_name(int kx0, int nl) {
+    if (nl == 2 && !bf16_four_waves()) return kx0 == 1 ? "gru_stack_bf16_ls<1> (both layers, one launch, 8 waves)" : "gru_stack_bf16_ls<2> (both layers, one launch, 8 waves)";
+    if (nl == 2) return kx0 == 1 ? "gru_stack_bf16<1, 2> (both layers, one launch, 4 waves)" : "gru_stack_bf16<2, 2> (both layers, one launch, 4 waves)";
+    return kx0 == 1 ? "gru_stack_bf16<1, 1>" : "gru_stack_bf16<2, 1>";
+}
+bool gru_bf16_vgpr_form() {
+#ifdef KWS_BF16_VGPR_FORM
+    return true;
+#else
+    return false;
+#endif
+}
+hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st) {
+    if (p.T <= 0 || p.B <= 0) return hipSuccess;   // the kernels prefetch frame min(t, T-1): nothing to run, nothing to read
+    // two layers: the layer-specialised 8-wave kernel (KWS_BF16_WAVES=4 keeps the 4-wave kernel for A/B)
+    const bool four = bf16_four_waves();
     if (nl == 2 && !four) {
         if (kx0 == 1) return launch_bf16_ls<1>(p, st);
         if (kx0 == 2) return launch_bf16_ls<2>(p, st);

@@ -16,6 +16,7 @@
 namespace {
 
 thread_local std::string g_last_error;
+thread_local bool g_in_selftest = false;      // kws_selftest creates temporary handles: no recursion through KWS_SELFTEST=1
 
 // Live handles (model / front-end / window): a stream handle borrows all three, and its owner may destroy one of them
 // first.  kws_stream_feed checks its borrowed pointers here -- pointer AND the serial it saw at kws_stream_create, so a new
@@ -114,6 +115,7 @@ struct kws_model {
     std::vector<hipEvent_t> event_pool;
     std::vector<float> ms_sum;
     std::vector<int32_t> launches;
+    std::string launch_name[8];      // kernel(s) the last kws_step launched per profiling slot (kws_last_launch)
 };
 
 struct kws_window {
@@ -238,7 +240,18 @@ inline int bf16_unit(int m, int g, int j) { return 32 * m + (j < 4 ? 4 * g + j :
 
 extern "C" {
 
-const char* kws_version(void) { return "kws_amd 0.3 (gfx950)"; }
+// Compiler provenance is part of the version string: the fp32 resident kernels rely on hand-placed hazard fences around
+// inline-asm MFMAs and gru_bf16.hip on an internal LLVM option (csrc/Makefile), so "which hipcc built this" is the first
+// thing to know when kws_selftest fails on a deployment.
+const char* kws_version(void) {
+    static const std::string v = [] {
+        char buf[384];
+        snprintf(buf, sizeof(buf), "kws_amd 0.4 (gfx950; HIP %d.%d.%d; %s; bf16 mfma-vgpr-form=%d)", HIP_VERSION_MAJOR, HIP_VERSION_MINOR,
+                 HIP_VERSION_PATCH, __VERSION__, kws::gru_bf16_vgpr_form() ? 1 : 0);
+        return std::string(buf);
+    }();
+    return v.c_str();
+}
 const char* kws_last_error(void) { return g_last_error.c_str(); }
 size_t kws_sizeof_config(void) { return sizeof(kws_config); }
 size_t kws_sizeof_frontend_config(void) { return sizeof(kws_frontend_config); }
@@ -461,6 +474,18 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
     m->ms_sum.assign(cfg->num_layers, 0.f);
     m->launches.assign(cfg->num_layers, 0);
     live_register(m);
+    // KWS_SELFTEST=1: every kws_create first proves the kernels this handle will use against the library's own known
+    // answers (kws_selftest below) -- a few milliseconds; meant for deployments on a ROCm other than the validated one
+    static const bool selftest_env = [] { const char* e = getenv("KWS_SELFTEST"); return e && e[0] == '1'; }();
+    if (selftest_env && !g_in_selftest) {
+        const int rc = kws_selftest(m);
+        if (rc != KWS_OK) {
+            const std::string keep = g_last_error;
+            kws_destroy(m);
+            g_last_error = keep;
+            return rc;
+        }
+    }
     *out = m;
     return KWS_OK;
 }
@@ -811,7 +836,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         // dynamic_rnn over zero frames hands the initial state back -- and clean_state() (detector.py:313-316) has already
         // zeroed it for the streams the mask names
         if (reset_mask) {
-            hipError_t e = kws::launch_state_passthrough(state_in, state_out, reset_mask, L, B, H, st);
+            hipError_t e = kws::launch_state_passthrough(state_in, state_out, reset_mask, prev_word, L, B, H, st);
             if (e != hipSuccess) return hip_fail(e, "launch state_passthrough");
         } else if (state_out != state_in) {
             KWS_HIP(hipMemcpyAsync(state_out, state_in, (size_t)L * B * H * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -854,6 +879,8 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         }
         hipError_t e = kws::launch_gru_stack_bf16(bp, h->bf_kx0, L, st);
         if (e != hipSuccess) return hip_fail(e, "launch gru_stack_bf16");
+        h->launch_name[0] = kws::gru_stack_bf16_kernel_name(h->bf_kx0, L);
+        for (int l = 1; l < L; ++l) h->launch_name[l].clear();
         if (h->profiling) {
             KWS_HIP(hipEventRecord(eb, st));
             h->pending.push_back({0, ea, eb});
@@ -950,6 +977,15 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             e = resident ? kws::launch_gru_layer_resident(p, first, last, st)
                          : kws::launch_gru_layer_generic(p, H, first, last, st);
             if (e != hipSuccess) return hip_fail(e, resident ? "launch gru_layer_resident" : "launch gru_layer_generic");
+        }
+        {
+            char nm[96];
+            if (pipelined) snprintf(nm, sizeof(nm), "gru_stack_generic_pipelined<%d> (all %d layers, one launch)", H / 64, L);
+            else if (int8 && h->oct[l].quantised) snprintf(nm, sizeof(nm), "gru_layer_octbit_kernel%s", l == L - 1 ? " + octbit_fc_kernel" : "");
+            else if (resident) snprintf(nm, sizeof(nm), "gru_layer_resident<%d, %s, %s>", p.KCX, first ? "true" : "false", last ? "true" : "false");
+            else snprintf(nm, sizeof(nm), "gru_layer_generic<%d, %s, %s>", H / 64, first ? "true" : "false", last ? "true" : "false");
+            h->launch_name[l] = nm;
+            if (pipelined) for (int k = 0; k < l; ++k) h->launch_name[k].clear();
         }
         if (int8 && l == L - 1) {
             kws::OctbitFcParams fp;
@@ -1436,4 +1472,228 @@ int kws_octbit_quantize(const float* W, int K, int N, int8_t* Wq, float* scale, 
     return KWS_OK;
 }
 
+
+int kws_last_launch(kws_handle h, int slot, char* buf, size_t n) {
+    if (!h || !buf || n == 0) return fail(KWS_ERR_INVALID_ARGUMENT, "null handle / buffer");
+    if (slot < 0 || slot >= h->cfg.num_layers) return fail(KWS_ERR_INVALID_ARGUMENT, "slot %d out of range [0,%d)", slot, h->cfg.num_layers);
+    snprintf(buf, n, "%s", h->launch_name[slot].c_str());
+    return KWS_OK;
+}
+
 }  // extern "C"
+
+// ---- kws_selftest ---------------------------------------------------------------------------------------------------
+// The kernels depend on things the compiler does not check: hand-placed wait states around inline-asm MFMAs (gru_device.h),
+// an internal LLVM option for gru_bf16.hip (csrc/Makefile).  A build by another ROCm can therefore be silently wrong; the
+// GPU test-suite catches that, a deployment has no test-suite.  So the library carries its own known answers: a plain
+// double-precision host loop of the cell (below; the published TF-1.x GRUCell, models/rnn_ctc.py:179-185,228-243) and
+// TensorFlow's own unit-test constants for it (rnn_cell_test.py testGRUCell / testMultiRNNCell: all kernels 0.5, gate bias
+// 1, candidate bias 0, x = 1, h = 0.1 -> 0.175991, 0.156736 for three inputs, 0.13248 from the second stacked cell).
+namespace {
+
+
+// (mel [B,T,I], state [L,B,H]) -> (logits [B,T,C], state'), canonical blob layout of kws_weights_nbytes; double throughout
+void host_forward(const kws_config& c, const float* blob, const float* mel, const float* st0, int B, int T,
+                  std::vector<double>& logits, std::vector<double>& state) {
+    const int H = c.hidden, L = c.num_layers, C = c.num_classes;
+    state.assign(st0, st0 + (size_t)L * B * H);
+    logits.assign((size_t)B * T * C, 0.0);
+    std::vector<double> x, g(2 * H), cand(H), hn(H);
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t) {
+            x.assign(mel + ((size_t)b * T + t) * c.n_mel, mel + ((size_t)b * T + t + 1) * c.n_mel);
+            const float* p = blob;
+            for (int l = 0; l < L; ++l) {
+                const int I = (int)x.size();
+                const float *Wg = p, *bg = Wg + (size_t)(I + H) * 2 * H, *Wc = bg + 2 * H, *bc = Wc + (size_t)(I + H) * H;
+                double* h = &state[((size_t)l * B + b) * H];
+                for (int j = 0; j < 2 * H; ++j) {
+                    double a = bg[j];
+                    for (int k = 0; k < I; ++k) a += x[k] * Wg[(size_t)k * 2 * H + j];
+                    for (int k = 0; k < H; ++k) a += h[k] * Wg[(size_t)(I + k) * 2 * H + j];
+                    g[j] = 1.0 / (1.0 + std::exp(-a));                          // [r | u]
+                }
+                for (int j = 0; j < H; ++j) {
+                    double a = bc[j];
+                    for (int k = 0; k < I; ++k) a += x[k] * Wc[(size_t)k * H + j];
+                    for (int k = 0; k < H; ++k) a += g[k] * h[k] * Wc[(size_t)(I + k) * H + j];   // r (.) h before the matmul
+                    cand[j] = std::tanh(a);
+                }
+                for (int j = 0; j < H; ++j) hn[j] = g[H + j] * h[j] + (1.0 - g[H + j]) * cand[j];
+                std::copy(hn.begin(), hn.end(), h);
+                x = hn;
+                p = bc + H;
+            }
+            const float *Wfc = p, *bfc = Wfc + (size_t)H * C;
+            for (int k = 0; k < C; ++k) {
+                double a = bfc[k];
+                for (int j = 0; j < H; ++j) a += x[j] * Wfc[(size_t)j * C + k];
+                if (c.use_relu) { a = std::max(a, 0.0); if (c.value_clip > 0) a = std::min(a, 20.0); }
+                logits[((size_t)b * T + t) * C + k] = a;
+            }
+        }
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+};
+
+// one case through kws_step on a temporary handle; *err_state / *err_logit = max abs deviation from the host loop
+int selftest_case(const kws_config& cfg, int kernel_kind, const std::vector<float>& blob, const std::vector<float>& mel,
+                  const std::vector<float>& st0, int B, int T, double* err_logit, double* err_state, std::vector<float>* state_out,
+                  std::string* kernels) {
+    const int H = cfg.hidden, L = cfg.num_layers, C = cfg.num_classes;
+    kws_handle m = nullptr;
+    int rc = kws_create(&cfg, blob.data(), blob.size() * sizeof(float), &m);
+    if (rc != KWS_OK) return rc;
+    rc = kws_set_kernel(m, kernel_kind);
+    DevBuf d_mel, d_st, d_lg;
+    std::vector<float> lg((size_t)B * T * C), st((size_t)L * B * H);
+    auto hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == KWS_OK) rc = hip_fail(e, what); };
+    if (rc == KWS_OK) {
+        hip(d_mel.alloc(mel.size() * 4), "selftest hipMalloc");
+        hip(d_st.alloc(st.size() * 4), "selftest hipMalloc");
+        hip(d_lg.alloc(lg.size() * 4), "selftest hipMalloc");
+    }
+    if (rc == KWS_OK) {
+        hip(hipMemcpy(d_mel.p, mel.data(), mel.size() * 4, hipMemcpyHostToDevice), "selftest upload");
+        hip(hipMemcpy(d_st.p, st0.data(), st0.size() * 4, hipMemcpyHostToDevice), "selftest upload");
+        hip(hipDeviceSynchronize(), "selftest sync");
+    }
+    if (rc == KWS_OK)
+        rc = kws_step(m, static_cast<const float*>(d_mel.p), static_cast<const float*>(d_st.p), static_cast<float*>(d_lg.p), nullptr,
+                      static_cast<float*>(d_st.p), nullptr, nullptr, nullptr, nullptr, 0.4f, B, T, nullptr);
+    if (rc == KWS_OK) {
+        hip(hipDeviceSynchronize(), "selftest kernels");
+        hip(hipMemcpy(lg.data(), d_lg.p, lg.size() * 4, hipMemcpyDeviceToHost), "selftest download");
+        hip(hipMemcpy(st.data(), d_st.p, st.size() * 4, hipMemcpyDeviceToHost), "selftest download");
+    }
+    if (rc == KWS_OK) rc = kws_poll_error(m);
+    if (rc == KWS_OK && kernels) {
+        kernels->clear();
+        for (int l = 0; l < L; ++l)
+            if (!m->launch_name[l].empty()) *kernels += (kernels->empty() ? "" : " + ") + m->launch_name[l];
+    }
+    const std::string keep = g_last_error;
+    kws_destroy(m);
+    if (rc != KWS_OK) { g_last_error = keep; return rc; }
+    std::vector<double> want_l, want_s;
+    host_forward(cfg, blob.data(), mel.data(), st0.data(), B, T, want_l, want_s);
+    double el = 0.0, es = 0.0;
+    for (size_t i = 0; i < lg.size(); ++i) { const double d = std::fabs(lg[i] - want_l[i]); el = (d > el || d != d) ? d : el; }
+    for (size_t i = 0; i < st.size(); ++i) { const double d = std::fabs(st[i] - want_s[i]); es = (d > es || d != d) ? d : es; }
+    *err_logit = el; *err_state = es;
+    if (state_out) *state_out = st;
+    return KWS_OK;
+}
+
+// deterministic pseudo-random floats in [-1, 1) (no <random>: identical on every libstdc++)
+struct Lcg {
+    uint64_t s;
+    float next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0); }
+};
+
+}  // namespace
+
+extern "C" int kws_selftest(kws_handle h) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (g_in_selftest) return KWS_OK;
+    struct Guard { Guard() { g_in_selftest = true; } ~Guard() { g_in_selftest = false; } } guard;
+    const kws_config cfg = h->cfg;
+    const int H = cfg.hidden, L = cfg.num_layers, C = cfg.num_classes, I0 = cfg.n_mel;
+    const size_t nfl = weights_floats(&cfg);
+    // tolerances: what the arithmetic of each precision leaves on these two cases (fp32: observed <= 4e-6 / 1e-7)
+    double tol_rand_logit, tol_rand_state, tol_kat;
+    switch (cfg.precision) {
+        case KWS_BF16: tol_rand_logit = 6e-2; tol_rand_state = 2e-2; tol_kat = 2e-3; break;
+        case KWS_INT8: tol_rand_logit = -1.0; tol_rand_state = -1.0; tol_kat = 2e-2; break;   // int8: known answers only
+        default:       tol_rand_logit = 5e-5; tol_rand_state = 2e-5; tol_kat = 1e-6; break;
+    }
+    std::vector<int> kinds;
+    if (cfg.precision == KWS_FP32) {
+        bool res_ok = true;
+        for (const auto& Ld : h->layers) res_ok &= Ld.resident_ok;
+        if (res_ok) kinds.push_back(KWS_KERNEL_RESIDENT);
+        kinds.push_back(KWS_KERNEL_GENERIC);
+    } else {
+        kinds.push_back(KWS_KERNEL_AUTO);
+    }
+    auto layer_off = [&](int l) { size_t o = 0; int in = I0; for (int k = 0; k < l; ++k) { o += (size_t)(in + H) * 3 * H + 3 * H; in = H; } return o; };
+    for (int kind : kinds) {
+        std::string kernels;
+        // (1) TensorFlow's published constants, the 2-unit test cell embedded in this shape: units 0,1 and inputs 0..n_in-1 live
+        for (int n_in = 2; n_in <= 3 && n_in <= I0; ++n_in) {
+            std::vector<float> blob(nfl, 0.f);
+            for (int l = 0; l < L; ++l) {
+                const int in = l == 0 ? I0 : H, live = l == 0 ? n_in : 2;
+                float* Wg = blob.data() + layer_off(l);
+                float* bg = Wg + (size_t)(in + H) * 2 * H;
+                float* Wc = bg + 2 * H;
+                for (int j = 0; j < 2 * H; ++j) bg[j] = 1.f;
+                for (int r = 0; r < live + 2; ++r) {
+                    const int row = r < live ? r : in + (r - live);
+                    for (int u = 0; u < 2; ++u) {
+                        Wg[(size_t)row * 2 * H + u] = 0.5f; Wg[(size_t)row * 2 * H + H + u] = 0.5f; Wc[(size_t)row * H + u] = 0.5f;
+                    }
+                }
+            }
+            float* Wfc = blob.data() + layer_off(L);
+            Wfc[0 * C + 0] = 1.f; Wfc[1 * C + 1] = 1.f;
+            const int B = 19, T = 1;
+            std::vector<float> mel((size_t)B * T * I0, 0.f), st0((size_t)L * B * H, 0.f), st;
+            for (int b = 0; b < B; ++b) {
+                for (int k = 0; k < n_in; ++k) mel[(size_t)b * I0 + k] = 1.f;
+                for (int l = 0; l < L; ++l) st0[((size_t)l * B + b) * H + 0] = st0[((size_t)l * B + b) * H + 1] = 0.1f;
+            }
+            double el, es;
+            const int rc = selftest_case(cfg, kind, blob, mel, st0, B, T, &el, &es, &st, &kernels);
+            if (rc != KWS_OK) return rc;
+            const double first = n_in == 2 ? 0.175991 : 0.156736;
+            double worst = 0.0;
+            for (int b = 0; b < B; ++b) {
+                for (int u = 0; u < 2; ++u) worst = std::max(worst, std::fabs(st[(size_t)b * H + u] - first));
+                if (L >= 2 && n_in == 2) for (int u = 0; u < 2; ++u) worst = std::max(worst, std::fabs(st[((size_t)B + b) * H + u] - 0.13248));
+                if (cfg.precision != KWS_INT8)
+                    for (int j = 2; j < H; ++j) if (st[(size_t)b * H + j] != 0.f) worst = 1.0;     // dead units stay exactly 0
+            }
+            if (!(worst <= tol_kat + 1e-6))
+                return fail(KWS_ERR_HIP, "kws_selftest: %s returns TensorFlow's published GRUCell constant (%g) with error %.3g (tolerance %.1g). "
+                            "This build (%s) computes wrong results on this device: rebuild with the ROCm release it was validated on, "
+                            "or run the repository's GPU tests.", kernels.c_str(), first, worst, tol_kat, kws_version());
+        }
+        // (2) 8 random frames of 19 streams against the host double-precision loop
+        if (tol_rand_logit > 0) {
+            Lcg rng{0x9e3779b97f4a7c15ull + (uint64_t)kind};
+            std::vector<float> blob(nfl);
+            for (int l = 0; l < L; ++l) {
+                const int in = l == 0 ? I0 : H;
+                float* Wg = blob.data() + layer_off(l);
+                float* bg = Wg + (size_t)(in + H) * 2 * H;
+                float* Wc = bg + 2 * H;
+                float* bc = Wc + (size_t)(in + H) * H;
+                const float ag = std::sqrt(6.f / (in + H + 2 * H)), ac = std::sqrt(6.f / (in + H + H));
+                for (size_t i = 0; i < (size_t)(in + H) * 2 * H; ++i) Wg[i] = ag * rng.next();
+                for (int j = 0; j < 2 * H; ++j) bg[j] = 1.f + 0.3f * rng.next();
+                for (size_t i = 0; i < (size_t)(in + H) * H; ++i) Wc[i] = ac * rng.next();
+                for (int j = 0; j < H; ++j) bc[j] = 0.3f * rng.next();
+            }
+            float* Wfc = blob.data() + layer_off(L);
+            for (int i = 0; i < H * C + C; ++i) Wfc[i] = rng.next();
+            const int B = 19, T = 8;
+            std::vector<float> mel((size_t)B * T * I0), st0((size_t)L * B * H);
+            for (auto& v : mel) v = 2.f * std::fabs(rng.next());
+            for (auto& v : st0) v = 0.5f * rng.next();
+            double el, es;
+            const int rc = selftest_case(cfg, kind, blob, mel, st0, B, T, &el, &es, nullptr, &kernels);
+            if (rc != KWS_OK) return rc;
+            if (!(el <= tol_rand_logit && es <= tol_rand_state))
+                return fail(KWS_ERR_HIP, "kws_selftest: %s differs from the host double-precision loop on 19 streams x 8 frames: max |dlogit| "
+                            "%.3g (tolerance %.1g), max |dstate| %.3g (tolerance %.1g). This build (%s) computes wrong results on this "
+                            "device: rebuild with the ROCm release it was validated on, or run the repository's GPU tests.",
+                            kernels.c_str(), el, tol_rand_logit, es, tol_rand_state, kws_version());
+        }
+    }
+    return KWS_OK;
+}

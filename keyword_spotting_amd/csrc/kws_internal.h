@@ -94,6 +94,8 @@ struct GruBf16Params {
 };
 bool gru_bf16_supported(int hidden, int n_mel, int layers);
 hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st);
+const char* gru_stack_bf16_kernel_name(int kx0, int nl);   // the kernel launch_gru_stack_bf16 picks (KWS_BF16_WAVES aware)
+bool gru_bf16_vgpr_form();                                  // built with -mllvm -amdgpu-mfma-vgpr-form=1 (csrc/Makefile)
 
 // int8 ("octbit") GRU layers and class projection (gru_octbit.hip)
 struct GruOctbitParams {
@@ -192,7 +194,8 @@ hipError_t launch_vad(const float* pcm, int B, int N, float thres, uint8_t* spee
                       hipStream_t st);
 
 // state_out = reset[b] ? 0 : state_in for [L,B,H] (a kws_step over zero frames; in-place allowed)
-hipError_t launch_state_passthrough(const float* state_in, float* state_out, const uint8_t* reset, int L, int B, int H, hipStream_t st);
+hipError_t launch_state_passthrough(const float* state_in, float* state_out, const uint8_t* reset, int32_t* prev_word, int L, int B, int H,
+                                    hipStream_t st);
 // ... and, fused into the same pass, the next sample carry: next [B,n_next] = the last n_next samples of [carry | chunk]
 // (n_next = 0: none)
 hipError_t launch_vad_gate(const void* pcm, int pcm_int16, int B, int N, float thres, float* pcm_f32, const uint8_t* restart,

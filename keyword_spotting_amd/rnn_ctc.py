@@ -104,6 +104,21 @@ class DeployModel(object):
         _lib.check(self._lib.kws_kernel_times(self._handle, ms, cnt, int(reset)))
         return [(float(ms[i]), int(cnt[i])) for i in range(n)]
 
+    def kernel_names(self):
+        """Kernel(s) the last forward() launched, per profiling slot ('' = ran inside another slot's launch)."""
+        out = []
+        for l in range(self.config.num_layers):
+            buf = ctypes.create_string_buffer(160)
+            _lib.check(self._lib.kws_last_launch(self._handle, l, buf, len(buf)))
+            out.append(buf.value.decode())
+        return out
+
+    def selftest(self):
+        """kws_selftest: the kernels this model launches against the library's own known answers (TensorFlow's published
+        GRUCell constants + a host double-precision loop); raises on mismatch.  KWS_SELFTEST=1 runs it in every create."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.kws_selftest(self._handle))
+
     # -- state -------------------------------------------------------------------------------
     def zero_state(self, batch=1):
         """detector.py:123-124 / clean_state :313-316, for `batch` streams."""

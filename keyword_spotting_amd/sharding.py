@@ -51,3 +51,31 @@ def count_ranks(dist, device):
     one = torch.ones(1, dtype=torch.int64, device=device)
     dist.all_reduce(one, op=dist.ReduceOp.SUM)
     return int(one.item())
+
+
+def rank_identity(rank, local_rank, device, frames_per_s):
+    """What one rank reports about itself in the bench line: host, the GPU it drove (uuid, else PCI bus id) and its own rate."""
+    import socket
+    import torch
+    info = {"rank": int(rank), "local_rank": int(local_rank), "host": socket.gethostname(), "device": str(device),
+            "device_id": None, "device_name": None, "mel_frames_per_s": float(frames_per_s)}
+    if getattr(device, "type", "cpu") == "cuda":
+        props = torch.cuda.get_device_properties(device)
+        info["device_name"] = props.name
+        ident = getattr(props, "uuid", None)
+        if ident is None or not str(ident).strip("0-"):
+            ident = "pci:%s:%s:%s" % (getattr(props, "pci_domain_id", "?"), getattr(props, "pci_bus_id", "?"),
+                                      getattr(props, "pci_device_id", "?"))
+        info["device_id"] = str(ident)
+    else:
+        info["device_id"] = "%s:pid%d" % (device, os.getpid())
+    return info
+
+
+def gather_rank_info(dist, info):
+    """[info of rank 0, ..., info of rank world-1] on every rank (all_gather_object after the timed region)."""
+    if dist is None or not dist.is_initialized():
+        return [info]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, info)
+    return out

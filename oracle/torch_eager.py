@@ -35,3 +35,33 @@ def gru_forward(tw, mel, state):
     top = torch.stack(tops, 1)
     logits = (top.reshape(-1, hdim) @ tw["Wfc"] + tw["bfc"]).reshape(mel.shape[0], mel.shape[1], -1)
     return logits, torch.softmax(logits, -1), torch.stack(hs)
+
+
+def eager_stream_rate(args):
+    """One pinned worker of bench.py's cpu_baseline leg (the eager stand-in on N cores, one
+    independent batch-1 stream per core): the detector-style loop -- 22-frame chunks, state round-tripping through
+    numpy -- for `seconds`, on CPU `cpu` (None: unpinned).  Returns mel-frames/s of this worker.  Top-level so that a
+    spawn-context process pool can import it."""
+    import os
+    import time
+    import numpy as np
+    cpu, seconds, n_mel, hidden, layers, classes = args
+    if cpu is not None:
+        try:
+            os.sched_setaffinity(0, {cpu})
+        except OSError:
+            pass
+    torch.set_num_threads(1)
+    from oracle import gru_oracle as G
+    tw = to_torch(G.init_weights(n_mel, hidden, layers, classes, seed=0))
+    mel = torch.from_numpy(G.synthetic_mel(1, 300, n_mel, seed=1))
+    state = torch.zeros(layers, 1, hidden)
+    for pos in range(0, 66, 22):                      # warm-up
+        gru_forward(tw, mel[:, pos:pos + 22], state)
+    frames, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for pos in range(0, 300, 22):
+            lg, sm, state = gru_forward(tw, mel[:, pos:pos + 22], state)
+            state = torch.from_numpy(np.array(state.numpy()))
+            frames += lg.shape[1]
+    return frames / (time.perf_counter() - t0)

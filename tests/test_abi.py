@@ -120,3 +120,70 @@ def test_stream_manager_entry_points_validate_arguments():
     assert lib.kws_stream_feed(None, None, 0, 0, None, None) == _lib.KWS_ERR_INVALID_ARGUMENT
     assert lib.kws_stream_reset(None) == _lib.KWS_ERR_INVALID_ARGUMENT
     assert lib.kws_stream_destroy(None) == _lib.KWS_OK
+
+
+def test_version_names_the_compiler_and_selftest_rejects_a_null_handle():
+    from keyword_spotting_amd import _lib
+    lib = _lib.load()
+    v = lib.kws_version().decode()
+    assert v.startswith("kws_amd ") and "gfx950" in v and "HIP " in v and "lang" in v and "mfma-vgpr-form=" in v
+    assert lib.kws_selftest(None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    buf = ctypes.create_string_buffer(64)
+    assert lib.kws_last_launch(None, 0, buf, 64) == _lib.KWS_ERR_INVALID_ARGUMENT
+
+
+_SELFTEST_SNIPPET = r"""
+import sys
+sys.path.insert(0, %r)
+from keyword_spotting_amd import _lib, get_config, weights
+from keyword_spotting_amd.rnn_ctc import DeployModel
+for kw in (dict(), dict(precision="bf16"), dict(precision="int8"), dict(n_mel=60, hidden_size=256, num_layers=4), dict(n_mel=60, num_layers=1)):
+    cfg = get_config(**kw)
+    try:
+        m = DeployModel(cfg, weights.init_weights(cfg, seed=0))
+        m.selftest()
+        print("PASS", kw)
+    except _lib.KwsError as e:
+        print("FAIL", kw, str(e)[:300])
+"""
+
+
+def _run_selftest_process(env_extra):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", _SELFTEST_SNIPPET % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [ln for ln in r.stdout.splitlines() if ln.startswith(("PASS", "FAIL"))]
+
+
+@pytest.mark.gpu
+def test_selftest_passes_on_this_build_for_every_precision_and_kernel_family():
+    """kws_selftest: TensorFlow's published GRUCell constants + a host fp64 loop, inside the library."""
+    lines = _run_selftest_process({})
+    assert len(lines) == 5 and all(ln.startswith("PASS") for ln in lines), lines
+    # ... and as the create-time hook (KWS_SELFTEST=1 is read once per process, hence the subprocess)
+    lines = _run_selftest_process({"KWS_SELFTEST": "1"})
+    assert len(lines) == 5 and all(ln.startswith("PASS") for ln in lines), lines
+
+
+@pytest.mark.gpu
+def test_selftest_catches_a_build_whose_mfma_fences_were_removed():
+    """The fp32 resident kernels need hand-placed wait states after their inline-asm MFMA chains (gru_device.h).  A variant
+    build without them (tools/patches/no_mfma_fence.patch) must be rejected by the self-test -- at kws_create with
+    KWS_SELFTEST=1 -- with a message that names the compiler."""
+    import shutil
+    import subprocess
+    so = os.path.join(ROOT, "variants", "libkws_nofence.so")
+    if not os.path.exists(so):
+        if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.skip("no hipcc to build the variant")
+        subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), "nofence", "--patch",
+                               os.path.join(ROOT, "tools", "patches", "no_mfma_fence.patch")])
+    lines = _run_selftest_process({"KWS_AMD_LIB": so})
+    fp32 = [ln for ln in lines if "precision" not in ln and "hidden_size" not in ln]     # the resident-kernel shapes
+    assert fp32 and all(ln.startswith("FAIL") for ln in fp32), lines
+    assert any("kws_selftest" in ln and "lang" in ln for ln in fp32), lines
+    lines = _run_selftest_process({"KWS_AMD_LIB": so, "KWS_SELFTEST": "1"})             # refused at kws_create
+    assert any(ln.startswith("FAIL") and "kws_selftest" in ln for ln in lines), lines

@@ -89,6 +89,12 @@ def test_bench_main_two_ranks_over_gloo_prints_one_line():
     assert line["ms_per_step"] >= 19.0
     assert abs(line["value"] - 2 * 64 * 10 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-6 * line["value"]
     assert "cpu_baseline" not in line                           # rank 0 at N=1 only
+    # every rank identifies itself: `world` entries, distinct (host, device) pairs, the slower rank visible
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1] and line["distinct_devices"] == 2
+    assert all(r["host"] and r["device_id"] for r in line["per_rank"])
+    assert line["per_rank"][1]["mel_frames_per_s"] < line["per_rank"][0]["mel_frames_per_s"]
+    # weak scaling, time = the slowest rank's: value ~ world x the slowest rank's own rate
+    assert abs(2 * min(r["mel_frames_per_s"] for r in line["per_rank"]) - line["value"]) < 0.2 * line["value"]
 
 
 def test_bench_main_under_an_external_torchrun_and_single_rank():
@@ -100,5 +106,6 @@ def test_bench_main_under_an_external_torchrun_and_single_rank():
                             "--warmup", "1", "--batch", "32", "--frames", "8", "--dist-backend", "gloo"])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
     one = _run_stub_bench([stub, "--steps", "3", "--warmup", "1", "--batch", "32", "--frames", "8", "--dist-backend", "gloo"])
-    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and len(one["per_rank"]) == 1
+    assert len(line["per_rank"]) == 2 and line["distinct_devices"] == 2
     assert abs(one["value"] - 32 * 8 * 3 / (one["ms_per_step"] * 3e-3)) < 1e-6 * one["value"]

@@ -99,6 +99,10 @@ def test_state_may_alias_and_empty_calls():
     st3 = st.clone()
     m.forward(mel[:, :0].contiguous(), st3, reset_mask=mask, state_out=st3)          # in place
     assert torch.equal(st3, e["state"])
+    # ... and their ctc_decode2 carry restarts from pre_word = -1, as a reset does in a call with frames
+    pw = torch.tensor([2, 2, 0, 1], dtype=torch.int32, device="cuda")
+    m.forward(mel[:, :0].contiguous(), st, reset_mask=mask, prev_word=pw)
+    assert pw.tolist() == [2, -1, 0, -1]
     e = m.forward(mel[:0].contiguous(), st[:, :0].contiguous())  # B == 0
     assert e["logits"].shape == (0, 9, 6)
 

@@ -41,7 +41,8 @@ for seed in range(seeds):
             bad += 1
             break
         fired += int(want.sum())
-    print("seed %2d %s n_mel=%d int16=%d b=%2d window=%2d label=%s: 40 chunks ok, %d triggers" % (seed, prec, n_mel, as_int16, b, win, label, fired), flush=True)
+    else:
+        print("seed %2d %s n_mel=%d int16=%d b=%2d window=%2d label=%s: 40 chunks ok, %d triggers" % (seed, prec, n_mel, as_int16, b, win, label, fired), flush=True)
     mgr.close()
 print("FAILED" if bad else "all %d seeds agree" % seeds)
 sys.exit(1 if bad else 0)
