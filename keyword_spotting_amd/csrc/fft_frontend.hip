@@ -92,9 +92,10 @@ constexpr int kSpecRows = 208;                 // spectrum rows (bins 0..200 + z
 // 52 MFMAs per 16 frames for 40 filters where the dense product takes 156.  Wave m = tile m.
 // 26 KiB of LDS per workgroup (the spectrum reuses the transpose planes): six workgroups = 24 waves per CU.
 // SampleT: float samples, or int16 PCM as the sound card delivers it (detector.py:40-43,74-79: scaled by 2^-15 on load --
-// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along -- one wave of workgroup
-// k takes the vad sum of stream k's new samples (the masks silent / reset) and writes its next sample carry; that pass is
-// HBM-bound where the transform is issue-bound, and it saves a launch (kws_stream_feed).
+// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along -- one wave of the
+// workgroup in which a stream's first frame lies takes the vad sum of that stream's new samples (the masks silent / reset)
+// and writes its next sample carry: the same rows this workgroup and its XCD neighbours transform, so the PCM is fetched
+// from HBM once (r3: the gate of stream k sat in workgroup k, on another XCD -- 1.7x the algorithmic read traffic).
 #ifndef KWS_FE_OCC
 #define KWS_FE_OCC 6          // workgroups per CU the register allocation aims at (tools/build_variant.sh -DKWS_FE_OCC=n for A/B)
 #endif
@@ -106,12 +107,18 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
     const int lane = tid & 63;
     const int hi = lane >> 4, lo = lane & 15;          // stage 1: (frame j of 4, n2); stage 2 / MFMA: (g, frame f of 16)
     const unsigned total = (unsigned)p.B * (unsigned)p.T;
-    const unsigned f0 = blockIdx.x * 16u;
+    // XCD-aware block -> frame-block map.  Workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2;
+    // a stream's frames span two or three 16-frame blocks, every frame re-reads 240 samples of its predecessor, and the
+    // gate below reads the whole row of a stream that starts in this block.  Giving XCD x the CONTIGUOUS run of blocks
+    // [x G/8, (x+1) G/8) keeps all readers of a row behind one L2, so the PCM leaves HBM once (the grid is a multiple of 8).
+    const unsigned blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned f0 = blk * 16u;
+    if (f0 >= total) return;                            // padding block of the rounded-up grid (uniform: before any barrier)
     constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
     const SampleT* chunk_all = sizeof(SampleT) == 2 ? reinterpret_cast<const SampleT*>(p.pcm_i16) : reinterpret_cast<const SampleT*>(p.pcm);
     const int n_chunk = p.n_samples - p.n_carry;
 #ifdef KWS_FE_TIMING       // tools/ubench/fe_phases.hip: s_memtime at the phase boundaries of every wave
-#define KWS_FE_STAMP(i) do { if (lane == 0) p.timing[((size_t)blockIdx.x * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define KWS_FE_STAMP(i) do { if (lane == 0) p.timing[((size_t)blk * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define KWS_FE_STAMP(i) do {} while (0)
 #endif
@@ -321,8 +328,11 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
         // The head of the stream-manager iteration, by the wave with the least to do after the last barrier (no mel tile
         // for 40 filters): workgroup k takes stream k's vad sum -- wave_abs_sum: the bits of kws_vad's block sum -- the
         // masks and the next carry while the other waves finish the projection.  No workgroup barrier: wave-private.
+        // The stream(s) whose FIRST frame lies in this block: their rows are what this workgroup (and its neighbours on the
+        // same XCD) transform, so the sum's reads are L2 hits or bring the row in for them.
         if (w == 3) {
-            for (int bs = blockIdx.x; bs < p.B; bs += gridDim.x) {
+            const unsigned T = (unsigned)p.T;
+            for (unsigned bs = (f0 + T - 1) / T; bs < (unsigned)p.B && bs * T < f0 + 16u; ++bs) {
                 const SampleT* row = chunk_all + (size_t)bs * n_chunk;
                 const float sum = wave_abs_sum<SampleT>(row, n_chunk, lane);
                 if (lane == 0) vad_masks(sum, p.vad_thres, bs, p.restart, p.silent, p.reset);
@@ -347,7 +357,7 @@ static hipError_t launch_fft400_tiles(const FrontendParams& p, unsigned grid, hi
 
 hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st) {
     const long long total = (long long)B * p.T;        // < 2^31 (checked by the caller)
-    const unsigned grid = (unsigned)((total + 15) / 16);
+    const unsigned grid = (unsigned)(((total + 15) / 16 + 7) / 8 * 8);     // multiple of 8: the kernel's XCD-aware block map
     if (p.pcm_i16) return p.gate ? launch_fft400_tiles<int16_t, true>(p, grid, st) : launch_fft400_tiles<int16_t, false>(p, grid, st);
     return p.gate ? launch_fft400_tiles<float, true>(p, grid, st) : launch_fft400_tiles<float, false>(p, grid, st);
 }
