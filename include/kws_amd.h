@@ -68,7 +68,12 @@ typedef struct kws_config {
                             octbit_mat_mul_op.cc:90-181 incl. the int16 pair saturation, activation range per
                             stream as the batch-1 graph has it; layer 0, biases, activations fp32; H=128) */
 } kws_config;
-enum { KWS_FP32 = 0, KWS_BF16 = 1, KWS_INT8 = 2 };
+enum { KWS_FP32 = 0, KWS_BF16 = 1, KWS_INT8 = 2,
+       /* fp32 results on the fp16 matrix pipe: every matmul operand split into two fp16 pieces (22 mantissa bits), three
+          v_mfma_f32_16x16x32_f16 per product, fp32 accumulation, activations and state (csrc/gru_f16x3.hip).  Meets the
+          fp32 path's tolerance (logits within 1e-4 of the reference semantics; observed ~3e-6) at ~2.5x its throughput;
+          it is NOT bit-identical to KWS_FP32.  hidden = 128, n_mel % 4 == 0 and <= 64, any num_layers; |weights| < 128. */
+       KWS_F16X3 = 3 };
 
 typedef struct kws_model* kws_handle;
 

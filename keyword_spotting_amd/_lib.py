@@ -13,7 +13,7 @@ KWS_ERR_NO_DEVICE = -4
 KWS_ERR_OUT_OF_MEMORY = -5
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_RESIDENT = 0, 1, 2
 DECODE, DECODE2, DECODE_STRICT = 0, 1, 2
-FP32, BF16, INT8 = 0, 1, 2
+FP32, BF16, INT8, F16X3 = 0, 1, 2, 3
 
 
 class KwsConfig(ctypes.Structure):

@@ -18,7 +18,7 @@ class Config(object):
         self.value_clip = -1.0                              # :80
         self.use_relu = False                               # :83
         self.hidden_size = 128                              # :84
-        self.precision = "fp32"                             # "fp32" (reference arithmetic) | "bf16" | "int8" (octbit graph) -- BASELINE configs[2]
+        self.precision = "fp32"                             # "fp32" (reference arithmetic) | "f16x3" (fp32 results on the fp16 matrix pipe, split operands) | "bf16" | "int8" (octbit graph) -- BASELINE configs[2]
         for k, v in overrides.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown config key %r" % k)

@@ -40,7 +40,7 @@ unsigned long long live_serial(const void* h) {      // 0: not a live handle
 }
 
 int fail(int code, const char* fmt, ...) {
-    char buf[512];
+    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
@@ -77,6 +77,10 @@ struct kws_model {
     // bf16 stack: offsets (floats) of the packed bf16 A operands
     size_t bf_w[2] = {0, 0}, bf_wfc = 0;
     int bf_kx0 = 0;
+    // f16x3 split stack: per layer the packed (hi, lo) fp16 A operands, and the projection's
+    std::vector<size_t> f16_w;
+    size_t f16_wfc = 0;
+    int f16_kx0 = 0;
     // int8 ("octbit") variant: per quantised layer the packed int16 couples + 127*colsum, and the projection
     struct OctLayer { bool quantised = false; size_t wg = 0, wc = 0, b127 = 0; float scale_g = 0.f, scale_c = 0.f; };
     std::vector<OctLayer> oct;
@@ -196,7 +200,11 @@ bool config_ok(const kws_config* c, int* code) {
         *code = fail(KWS_ERR_UNSUPPORTED, "int8 path needs hidden=128 (OctbitMatMul K=2*hidden must be a multiple of 64 and the kernel is built for 128); got %d", c->hidden);
         return false;
     }
-    if (c->precision != KWS_FP32 && c->precision != KWS_BF16 && c->precision != KWS_INT8) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "unknown precision %d", c->precision); return false; }
+    if (c->precision != KWS_FP32 && c->precision != KWS_BF16 && c->precision != KWS_INT8 && c->precision != KWS_F16X3) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "unknown precision %d", c->precision); return false; }
+    if (c->precision == KWS_F16X3 && !kws::gru_f16x3_supported(c->hidden, c->n_mel)) {
+        *code = fail(KWS_ERR_UNSUPPORTED, "f16x3 path needs hidden=128 and n_mel%%4==0, 4..64; got hidden=%d n_mel=%d", c->hidden, c->n_mel);
+        return false;
+    }
     if (c->precision == KWS_BF16 && !kws::gru_bf16_supported(c->hidden, c->n_mel, c->num_layers)) {
         *code = fail(KWS_ERR_UNSUPPORTED, "bf16 path needs hidden=128, num_layers<=2, n_mel%%4==0 and <=64; got hidden=%d layers=%d n_mel=%d",
                      c->hidden, c->num_layers, c->n_mel);
@@ -232,6 +240,23 @@ inline uint16_t bf16_rne(float x) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+// fp32 -> fp16 bits, round to nearest even (what v_cvt_f16_f32 does); the host compiler is clang: _Float16 is native
+inline uint16_t f16_rne(float x) {
+    const _Float16 h = static_cast<_Float16>(x);
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+inline float f16_value(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return static_cast<float>(h);
+}
+// v = hi + 2^-11 lo (gru_f16x3.hip): the two fp16 pieces of a weight
+inline void f16_split(float v, uint16_t* hi, uint16_t* lo) {
+    *hi = f16_rne(v);
+    *lo = f16_rne((v - f16_value(*hi)) * 2048.0f);
 }
 // unit of a hidden vector addressed by (chunk m, lane group g, element j) in the bf16 exchange layout
 inline int bf16_unit(int m, int g, int j) { return 32 * m + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)); }
@@ -389,6 +414,62 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
                 for (int j = 0; j < 8; ++j) {
                     const int g = lane >> 4, i = lane & 15;
                     dst[((size_t)c * 64 + lane) * 8 + j] = bf16_rne(i < C ? Wfc[(size_t)bf16_unit(c, g, j) * C + i] : 0.f);
+                }
+    }
+
+    if (cfg->precision == KWS_F16X3) {
+        // A operands of v_mfma_f32_16x16x32_f16, split: [8 tiles][3 gates][kc chunks][hi|lo][64 lanes] x 8 halves; lane (g,i)
+        // holds W[row(c,g,j)][16n+i], j = 0..7, rows in gru_bf16's K permutation.  The first layer's x-part is scaled by 2^8
+        // (the kernel feeds mel * 2^-8: both exact) so that mel magnitudes far beyond fp16's 65504 stay representable.
+        const float* q = static_cast<const float*>(weights_blob);
+        for (size_t i = 0; i < weights_floats(cfg); ++i)
+            if (!(std::fabs(q[i]) < 128.0f)) {
+                delete m;
+                return fail(KWS_ERR_UNSUPPORTED, "f16x3 path: weight %zu = %g is outside (-128, 128) (fp16 operands; x-part scaled by 256)", i, (double)q[i]);
+            }
+        int in_l = cfg->n_mel;
+        m->f16_kx0 = (cfg->n_mel + 31) / 32;
+        for (int l = 0; l < cfg->num_layers; ++l) {
+            const float* Wg = q;
+            const float* Wc = Wg + (size_t)(in_l + H) * 2 * H + 2 * H;
+            const int kx = l == 0 ? m->f16_kx0 : 4, kc = kx + 4;
+            m->f16_w.push_back(reserve((size_t)8 * 3 * kc * 2 * 64 * 4));
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&host[m->f16_w[l]]);
+            for (int n = 0; n < 8; ++n)
+                for (int gq = 0; gq < 3; ++gq)
+                    for (int c = 0; c < kc; ++c)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int g = lane >> 4, i = lane & 15;
+                                int row;
+                                bool ok = true;
+                                float scale = 1.f;
+                                if (c < kx) {
+                                    if (l == 0) { row = 32 * c + 8 * g + j; ok = row < in_l; scale = 256.f; }
+                                    else row = bf16_unit(c, g, j);
+                                } else {
+                                    row = in_l + bf16_unit(c - kx, g, j);
+                                }
+                                const float v = ok ? scale * wq(Wg, Wc, H, gq, row, n * 16 + i) : 0.f;
+                                uint16_t hi, lo;
+                                f16_split(v, &hi, &lo);
+                                const size_t base = (((size_t)(n * 3 + gq) * kc + c) * 2) * 64;
+                                dst[(base + lane) * 8 + j] = hi;
+                                dst[(base + 64 + lane) * 8 + j] = lo;
+                            }
+            q = Wc + (size_t)(in_l + H) * H + H;
+            in_l = H;
+        }
+        m->f16_wfc = reserve((size_t)4 * 2 * 64 * 4);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(&host[m->f16_wfc]);
+        for (int c = 0; c < 4; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = lane >> 4, i = lane & 15;
+                    uint16_t hi, lo;
+                    f16_split(i < C ? Wfc[(size_t)bf16_unit(c, g, j) * C + i] : 0.f, &hi, &lo);
+                    dst[(((size_t)c * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                    dst[(((size_t)c * 2 + 1) * 64 + lane) * 8 + j] = lo;
                 }
     }
 
@@ -844,7 +925,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         return KWS_OK;
     }
     if (!mel) return fail(KWS_ERR_INVALID_ARGUMENT, "mel is null");
-    if (c.precision != KWS_BF16) {
+    if (c.precision != KWS_BF16 && c.precision != KWS_F16X3) {
         // the streaming kernels address a group's seam (T x H/16 KiB) through buffer instructions with 32-bit offsets
         bool streaming = false;
         for (const auto& Ld : h->layers)
@@ -888,6 +969,48 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         return KWS_OK;
     }
     if ((reinterpret_cast<uintptr_t>(mel) & 15) != 0) return fail(KWS_ERR_INVALID_ARGUMENT, "mel must be 16-byte aligned");
+    if (c.precision == KWS_F16X3) {
+        // one launch per layer; the seams (same size as the fp32 ones) hold the layer outputs already split into fp16 pairs
+        int rc = ensure_scratch(h, B, T);
+        if (rc != KWS_OK) return rc;
+        for (int l = 0; l < L; ++l) {
+            const bool first = l == 0, last = l == L - 1;
+            kws::GruF16Params fp;
+            memset(&fp, 0, sizeof(fp));
+            fp.w = reinterpret_cast<const uint4*>(h->d_weights + h->f16_w[l]);
+            fp.bias = h->d_weights + h->layers[l].bias;
+            fp.wfc = reinterpret_cast<const uint4*>(h->d_weights + h->f16_wfc);
+            fp.bfc = h->d_weights + h->bfc_off;
+            fp.x_mel = mel;
+            fp.x_prev = first ? nullptr : reinterpret_cast<const uint4*>(h->scratch[(l - 1) % h->nscratch]);
+            fp.h_out = last ? nullptr : reinterpret_cast<uint4*>(h->scratch[l % h->nscratch]);
+            fp.state_in = state_in + (size_t)l * B * H;
+            fp.state_out = state_out + (size_t)l * B * H;
+            fp.seq_len = seq_len; fp.reset = reset_mask;
+            fp.epi.logits = logits; fp.epi.softmax = softmax; fp.epi.tokens = tokens; fp.epi.prev_word = prev_word;
+            fp.epi.decode_thres = decode2_thres; fp.epi.value_clip = c.value_clip; fp.epi.use_relu = c.use_relu;
+            fp.epi.B = B; fp.epi.T = T; fp.epi.C = c.num_classes;
+            fp.B = B; fp.T = T; fp.I = h->layers[l].in_dim;
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (h->profiling) {
+                for (hipEvent_t* ev : {&ea, &eb}) {
+                    if (!h->event_pool.empty()) { *ev = h->event_pool.back(); h->event_pool.pop_back(); }
+                    else KWS_HIP(hipEventCreate(ev));
+                }
+                KWS_HIP(hipEventRecord(ea, st));
+            }
+            hipError_t e = kws::launch_gru_layer_f16x3(fp, first, last, st);
+            if (e != hipSuccess) return hip_fail(e, "launch gru_layer_f16x3");
+            char nm[96];
+            snprintf(nm, sizeof(nm), "gru_layer_f16x3<%d, %s, %s>", first ? h->f16_kx0 : 4, first ? "true" : "false", last ? "true" : "false");
+            h->launch_name[l] = nm;
+            if (h->profiling) {
+                KWS_HIP(hipEventRecord(eb, st));
+                h->pending.push_back({l, ea, eb});
+            }
+        }
+        return KWS_OK;
+    }
     if (overlap_eligible(h, B, T))
         return step_overlapped(h, mel, state_in, logits, softmax, state_out, seq_len, reset_mask, tokens, prev_word,
                                decode2_thres, B, T, st);
@@ -1609,7 +1732,7 @@ extern "C" int kws_selftest(kws_handle h) {
     switch (cfg.precision) {
         case KWS_BF16: tol_rand_logit = 6e-2; tol_rand_state = 2e-2; tol_kat = 2e-3; break;
         case KWS_INT8: tol_rand_logit = -1.0; tol_rand_state = -1.0; tol_kat = 2e-2; break;   // int8: known answers only
-        default:       tol_rand_logit = 5e-5; tol_rand_state = 2e-5; tol_kat = 1e-6; break;
+        default:       tol_rand_logit = 5e-5; tol_rand_state = 2e-5; tol_kat = 1e-6; break;   // fp32 and the f16x3 split
     }
     std::vector<int> kinds;
     if (cfg.precision == KWS_FP32) {

@@ -97,6 +97,25 @@ hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStr
 const char* gru_stack_bf16_kernel_name(int kx0, int nl);   // the kernel launch_gru_stack_bf16 picks (KWS_BF16_WAVES aware)
 bool gru_bf16_vgpr_form();                                  // built with -mllvm -amdgpu-mfma-vgpr-form=1 (csrc/Makefile)
 
+// "f16x3": fp32-accuracy stack on the fp16 matrix pipe, operands split hi + 2^-11 lo (gru_f16x3.hip); one layer per launch
+struct GruF16Params {
+    const uint4* w;         // [8 tiles][3 gates][KX + 4 chunks][hi|lo][64 lanes] f16x8 A operands (x chunks first)
+    const float* bias;      // [3][128] fp32
+    const uint4* wfc;       // LAST: [4 chunks][hi|lo][64]  Wfc^T padded to 16 rows
+    const float* bfc;       // [16]
+    const float* x_mel;     // FIRST: [B,T,I]
+    const uint4* x_prev;    // !FIRST: the layer below's output, split, B-operand order: [G][T][4 chunks][hi|lo][64 lanes]
+    uint4* h_out;           // !LAST: this layer's output, same layout
+    const float* state_in;  // [B,128] of this layer
+    float* state_out;
+    const int32_t* seq_len;
+    const uint8_t* reset;
+    GruLayerParams epi;     // LAST: logits / softmax / tokens / prev_word / thresholds for the epilogue
+    int B, T, I;
+};
+bool gru_f16x3_supported(int hidden, int n_mel);
+hipError_t launch_gru_layer_f16x3(const GruF16Params& p, bool first, bool last, hipStream_t st);
+
 // int8 ("octbit") GRU layers and class projection (gru_octbit.hip)
 struct GruOctbitParams {
     const uint32_t* wg;     // gates  [4 K-quarters][2 unit groups][2 units per lane][32 = 16 couples x (even,odd)][64 lanes]  int16 pairs

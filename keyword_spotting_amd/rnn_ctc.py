@@ -45,7 +45,7 @@ class DeployModel(object):
         blob = np.ascontiguousarray(blob, np.float32)
         self._cfg = _lib.KwsConfig(config.n_mel, config.hidden_size, config.num_layers, config.num_classes,
                                    int(bool(config.use_relu)), float(config.value_clip),
-                                   {"fp32": _lib.FP32, "bf16": _lib.BF16, "int8": _lib.INT8}[getattr(config, "precision", "fp32")])
+                                   {"fp32": _lib.FP32, "bf16": _lib.BF16, "int8": _lib.INT8, "f16x3": _lib.F16X3}[getattr(config, "precision", "fp32")])
         self._handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.kws_create(ctypes.byref(self._cfg), blob.ctypes.data_as(ctypes.c_void_p),

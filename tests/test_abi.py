@@ -144,7 +144,7 @@ for kw in (dict(), dict(precision="bf16"), dict(precision="int8"), dict(n_mel=60
         m.selftest()
         print("PASS", kw)
     except _lib.KwsError as e:
-        print("FAIL", kw, str(e)[:300])
+        print("FAIL", kw, str(e)[:900])
 """
 
 

@@ -15,6 +15,8 @@ def _model(shape, w, kernel="auto", **cfg_kw):
     from keyword_spotting_amd import get_config
     from keyword_spotting_amd.rnn_ctc import DeployModel
     i, h, l, c = shape
+    if kernel == "f16x3":        # the split-fp16 path has to meet every fp32 tolerance: it rides along as a "kernel" here
+        kernel, cfg_kw = "auto", dict(cfg_kw, precision="f16x3")
     cfg = get_config(n_mel=i, hidden_size=h, num_layers=l, **cfg_kw)
     if c != 6:
         cfg.label_dict = {str(k): k for k in range(1, c - 2)}
@@ -26,14 +28,17 @@ def _cfg_tuple(shape, use_relu=0, clip=-1.0):
 
 
 SHAPES = {"A": (40, 128, 2, 6), "B": (60, 128, 2, 6), "C": (60, 256, 4, 6),
-          "D": (64, 128, 2, 6), "E": (32, 128, 1, 6), "F": (48, 128, 3, 6)}     # the other resident front-end widths
+          "D": (64, 128, 2, 6), "E": (32, 128, 1, 6), "F": (48, 128, 3, 6),     # the other resident front-end widths
+          "G": (12, 128, 4, 5)}                                                 # f16x3 only: narrow input, four layers, C = 5
 
 
 @pytest.mark.parametrize("name,kernel,batch,frames", [
     ("A", "resident", 37, 50), ("A", "generic", 37, 50), ("A", "resident", 1, 300),
     ("A", "resident", 16, 1), ("A", "resident", 33, 7), ("B", "resident", 20, 23), ("B", "generic", 5, 22),
     ("C", "generic", 20, 12), ("C", "auto", 3, 40),
-    ("D", "resident", 19, 30), ("E", "resident", 35, 26), ("F", "resident", 8, 41)])
+    ("D", "resident", 19, 30), ("E", "resident", 35, 26), ("F", "resident", 8, 41),
+    ("A", "f16x3", 37, 50), ("A", "f16x3", 1, 300), ("A", "f16x3", 16, 1), ("A", "f16x3", 33, 7), ("B", "f16x3", 20, 23),
+    ("D", "f16x3", 19, 30), ("E", "f16x3", 35, 26), ("F", "f16x3", 8, 41), ("G", "f16x3", 21, 19)])
 def test_logits_state_softmax_match_oracle(oracle_c, name, kernel, batch, frames):
     shape = SHAPES[name]
     i, h, l, c = shape
@@ -63,7 +68,7 @@ def test_resident_and_generic_kernels_agree():
     assert (ra["state"] - rb["state"]).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("kernel", ["resident", "generic"])
+@pytest.mark.parametrize("kernel", ["resident", "generic", "f16x3"])
 def test_chunked_streaming_equals_one_shot_bitwise(kernel):
     """detector.py:254-289 test2: feeding 21/22/23-frame chunks with the carried state must give the
     single-call result -- bit-exact on the GPU, every frame runs the identical instruction sequence."""
@@ -81,9 +86,10 @@ def test_chunked_streaming_equals_one_shot_bitwise(kernel):
     assert torch.equal(state, whole["state"])
 
 
-def test_state_may_alias_and_empty_calls():
+@pytest.mark.parametrize("kernel", ["auto", "f16x3"])
+def test_state_may_alias_and_empty_calls(kernel):
     w = G.init_weights()
-    m = _model(SHAPES["A"], w)
+    m = _model(SHAPES["A"], w, kernel)
     mel = torch.from_numpy(G.synthetic_mel(4, 9)).cuda()
     st = (0.1 * torch.randn(2, 4, 128, device="cuda"))
     ref = m.forward(mel, st.clone())
@@ -107,7 +113,7 @@ def test_state_may_alias_and_empty_calls():
     assert e["logits"].shape == (0, 9, 6)
 
 
-@pytest.mark.parametrize("kernel", ["resident", "generic"])
+@pytest.mark.parametrize("kernel", ["resident", "generic", "f16x3"])
 def test_sequence_length_and_reset_mask(kernel):
     w = G.random_weights(40, 128, 2, 6, seed=41)
     b, t = 21, 30
@@ -130,12 +136,13 @@ def test_sequence_length_and_reset_mask(kernel):
         np.testing.assert_array_equal(got[k, lens[k]:], np.broadcast_to(w["bfc"], (t - lens[k], 6)))
 
 
-def test_relu_and_clip():
+@pytest.mark.parametrize("kernel", ["auto", "f16x3"])
+def test_relu_and_clip(kernel):
     w = G.random_weights(40, 128, 2, 6, seed=51)
     w["Wfc"] *= 20
     mel = G.synthetic_mel(6, 25, 40, seed=52)
     want, _ = G.gru_forward(w, mel, use_relu=True, value_clip=1.0, dtype=np.float64)
-    m = _model(SHAPES["A"], w, use_relu=True, value_clip=1.0)
+    m = _model(SHAPES["A"], w, kernel, use_relu=True, value_clip=1.0)
     got = m.forward(torch.from_numpy(mel), m.zero_state(6))["logits"].cpu().numpy()
     assert np.abs(got - want).max() < 2e-3 * 20 / 20 + 5e-4      # logits up to 20: relative 1e-4-class
     assert got.min() == 0.0 and got.max() == 20.0
@@ -147,7 +154,7 @@ def _margin_ok(softmax_row, thres, eps=1e-4):
     return abs(p.max() - thres) > eps and (srt[-1] - srt[-2]) > eps
 
 
-@pytest.mark.parametrize("kernel", ["resident", "generic"])
+@pytest.mark.parametrize("kernel", ["resident", "generic", "f16x3"])
 def test_fused_decode2_tokens_and_carry(kernel):
     """Fused per-frame ctc_decode2 events == reference rule on the oracle's softmax; pre_word is
     carried across chunk boundaries (== decoding the concatenation)."""
@@ -216,7 +223,8 @@ def test_session_run_surface_batch1():
     assert np.abs(softmax.cpu().numpy() - G.softmax(want_l)[0]).max() < 2e-5
 
 
-def test_full_size_properties(oracle_c):
+@pytest.mark.parametrize("kernel", ["auto", "f16x3"])
+def test_full_size_properties(oracle_c, kernel):
     """BASELINE config 2 at full size (B=4096, T=300): (i) a sample of streams against the C oracle,
     (ii) batch-composition independence: a stream's result does not depend on its batch neighbours
     (what multi-GPU sharding relies on), (iii) chunked == one-shot, bitwise."""
@@ -224,7 +232,7 @@ def test_full_size_properties(oracle_c):
     b, t = 4096, 300
     rng = torch.Generator(device="cpu").manual_seed(71)
     mel = (torch.randn(b, t, 40, generator=rng).abs() * 2).cuda()
-    m = _model(SHAPES["A"], w)
+    m = _model(SHAPES["A"], w, kernel)
     whole = m.forward(mel, m.zero_state(b))
     pick = [0, 1, 15, 16, 17, 2047, 2048, 4079, 4080, 4095] + list(range(100, 4000, 211))
     sub = mel[pick].cpu().numpy()
@@ -243,7 +251,7 @@ def test_full_size_properties(oracle_c):
     assert torch.equal(state, whole["state"])
 
 
-@pytest.mark.parametrize("kernel,precision", [("resident", "fp32"), ("generic", "fp32"), ("auto", "bf16")])
+@pytest.mark.parametrize("kernel,precision", [("resident", "fp32"), ("generic", "fp32"), ("auto", "bf16"), ("auto", "f16x3")])
 def test_saturating_inputs_stay_finite_and_match_the_oracle(kernel, precision):
     """Mel frames of magnitude 1e3..1e4 drive every gate deep into saturation: exp2 overflows to inf and the reciprocal
     returns 0 -- sigmoid/tanh must land exactly on 0 / 1 / -1 like the oracle's, never on NaN."""
@@ -256,7 +264,7 @@ def test_saturating_inputs_stay_finite_and_match_the_oracle(kernel, precision):
     r = m.forward(torch.from_numpy(mel), torch.from_numpy(st0))
     got_l, got_s = r["logits"].cpu().numpy(), r["state"].cpu().numpy()
     assert np.isfinite(got_l).all() and np.isfinite(got_s).all() and np.isfinite(r["softmax"].cpu().numpy()).all()
-    if precision == "fp32":
+    if precision in ("fp32", "f16x3"):
         want_l, want_s = G.gru_forward(w, mel, st0, dtype=np.float64)
         tol_l, tol_s = 5e-4, 1e-4        # layer-0 pre-activations ~1e4: fp32 products carry ~1e-3 absolute, gates are saturated
     else:
@@ -264,3 +272,45 @@ def test_saturating_inputs_stay_finite_and_match_the_oracle(kernel, precision):
         tol_l, tol_s = 8e-2, 3e-2
     assert np.abs(got_s - want_s).max() < tol_s and np.abs(got_l - want_l).max() < tol_l
     np.testing.assert_allclose(r["softmax"].cpu().numpy().sum(-1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 3e2, 1e5, 1e6])
+def test_f16x3_covers_the_mel_dynamic_range(scale):
+    """The split path feeds the matrix pipe fp16 pieces of mel * 2^-8: magnitudes from 1e-6 to 1e7 (fp16 alone ends at 65504; the largest sample here is ~9e6)
+    must still meet the fp32 tolerance -- weights scaled down so that the gates do not simply saturate; above 1.6e7 the input
+    saturates (finite results, documented)."""
+    w = G.random_weights(40, 128, 2, 6, seed=81)
+    for lay in w["layers"][:1]:
+        lay["Wg"][:40] *= np.float32(min(1.0, 1.0 / scale))
+        lay["Wc"][:40] *= np.float32(min(1.0, 1.0 / scale))
+    b, t = 18, 24
+    mel = (G.synthetic_mel(b, t, 40, seed=82) * np.float32(scale)).astype(np.float32)
+    want_l, want_s = G.gru_forward(w, mel, dtype=np.float64)
+    m = _model(SHAPES["A"], w, "f16x3")
+    r = m.forward(torch.from_numpy(mel), m.zero_state(b))
+    assert np.abs(r["logits"].cpu().numpy() - want_l).max() < TOL
+    assert np.abs(r["state"].cpu().numpy() - want_s).max() < TOL
+    huge = m.forward(torch.from_numpy(mel * np.float32(1e30 / scale)), m.zero_state(b))
+    assert torch.isfinite(huge["logits"]).all() and torch.isfinite(huge["state"]).all()
+
+
+def test_f16x3_preconditions_and_its_distance_from_the_fp32_kernels():
+    from keyword_spotting_amd import _lib
+    w = G.init_weights()
+    big = {k: v for k, v in w.items()}
+    big["layers"] = [dict(lay) for lay in w["layers"]]
+    big["layers"][1]["Wc"] = big["layers"][1]["Wc"].copy()
+    big["layers"][1]["Wc"][3, 5] = 200.0
+    with pytest.raises(_lib.UnsupportedError):
+        _model(SHAPES["A"], big, "f16x3")                         # |w| >= 128 is outside the fp16 pieces' range
+    with pytest.raises(_lib.UnsupportedError):
+        _model(SHAPES["C"], G.init_weights(60, 256, 4, 6), "f16x3")   # hidden 256
+    mel = torch.from_numpy(G.synthetic_mel(64, 300, 40, seed=83))
+    a, f = _model(SHAPES["A"], w, "resident"), _model(SHAPES["A"], w, "f16x3")
+    ra = a.forward(mel, a.zero_state(64), prev_word=a.fresh_prev_word(64))
+    rf = f.forward(mel, f.zero_state(64), prev_word=f.fresh_prev_word(64))
+    d = (ra["logits"] - rf["logits"]).abs().max().item()
+    print("f16x3 vs fp32 resident kernels, 64 streams x 300 frames: max |dlogit| %.2e, token frames differing %d of %d"
+          % (d, int((ra["tokens"] != rf["tokens"]).sum()), ra["tokens"].numel()))
+    assert d < 2e-5                                               # not bit-identical (another summation order), fp32-rounding close
+    assert f.kernel_names() == ["gru_layer_f16x3<2, true, false>", "gru_layer_f16x3<4, false, true>"]
