@@ -40,10 +40,10 @@ __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-// A operand straight from AGPRs (see KWS_MFMA_A in gru_device.h for the hazard rule: chains start with mfma_prefence and
-// end with mfma_fence)
-#define KWS_MFMA_F16_A(acc, wa, bv) \
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(wa), "v"(bv))
+// Resident operands are pinned into AGPRs once (asm "+a" at load time); with MFMA results in VGPRs (csrc/Makefile builds this
+// file with -amdgpu-mfma-vgpr-form, as gru_bf16.hip) hipcc then feeds the BUILTIN MFMA straight from the "a" registers -- no
+// v_accvgpr_read copies (checked in the ISA) -- and, unlike inline-asm MFMAs, it sees every hazard and can interleave the
+// matrix instructions with the activation arithmetic, which is what the frame loop below is arranged for.
 
 __device__ __forceinline__ void split2(f32x2 x, unsigned& hi, unsigned& lo) {
     const f16x2 h = __builtin_convertvector(x, f16x2);
@@ -64,6 +64,19 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi
 }
 __device__ __forceinline__ f32x4 combine(const f32x4& m, const f32x4& l) { return m + l * kLoInv; }
 
+// Scheduling regions.  sched_barrier(0): nothing crosses.  interleave<N, M, V>: N times {M matrix instructions, then V VALU
+// instructions} for the instructions of the enclosing region, in dependency order -- an MFMA occupies the matrix pipe for
+// ~17 cycles during which the wave may issue VALU work of its own, but only when the two alternate in the stream (in-order issue).
+__device__ __forceinline__ void region_fence() { __builtin_amdgcn_sched_barrier(0); }
+template <int N, int M, int V>
+__device__ __forceinline__ void interleave() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+    }
+}
+
 enum { kInAgpr = 0, kInVgpr = 1, kInLds = 2 };
 // where gate q's x-part operands of a layer with KX x-chunks live
 template <int KX, bool FIRST>
@@ -77,7 +90,7 @@ constexpr int x_place(int q) {
 
 size_t gru_f16x3_lds_bytes(int kx, bool first, bool last) {
     size_t n = 2 * 4 * 2 * 64 * 16;                      // hb, rhb
-    n += (size_t)kx * 2 * 64 * 16;                       // xsb
+    n += (size_t)2 * kx * 2 * 64 * 16;                   // xsb, two slots
     if (!first) n += (size_t)4 * 16 * 64 * 16;           // u-gate x-part operands, per wave
     n += 3 * 128 * 4;                                    // biases
     if (last) n += kEpilogueLdsBytes;
@@ -97,8 +110,8 @@ gru_layer_f16x3(const GruF16Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* hb = reinterpret_cast<u32x4*>(smem);              // [4 chunks][hi|lo][64]   h_{t-1}
     u32x4* rhb = hb + 4 * 2 * 64;                             // [4][2][64]              r (.) h_{t-1}
-    u32x4* xsb = rhb + 4 * 2 * 64;                            // [KX][2][64]             this frame's input
-    u32x4* wul = xsb + KX * 2 * 64;                           // !FIRST: [4 waves][2 tiles][KX][2][64]  u-gate x-part
+    u32x4* xsb = rhb + 4 * 2 * 64;                            // [2 slots][KX][2][64]    input of frames t+1, t+2 (ping-pong)
+    u32x4* wul = xsb + 2 * KX * 2 * 64;                         // !FIRST: [4 waves][2 tiles][KX][2][64]  u-gate x-part
     float* biasl = reinterpret_cast<float*>(wul + (FIRST ? 0 : 4 * 2 * KX * 2 * 64));   // [3][128]
     const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * H));      // LAST only
 
@@ -140,7 +153,7 @@ gru_layer_f16x3(const GruF16Params p) {
         if (w == 0) bfc4 = ld4(p.bfc + 4 * g);
     }
     for (int i = tid; i < 3 * H; i += 256) biasl[i] = p.bias[i];
-    for (int i = tid; i < KX * 2 * 64; i += 256) xsb[i] = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * KX * 2 * 64; i += 256) xsb[i] = (u32x4){0u, 0u, 0u, 0u};
     const f32x4* bl = reinterpret_cast<const f32x4*>(biasl);
 
     // ---- input fetch: FIRST: wave w brings streams 4w..4w+3 of the mel frame (one dwordx4 per lane), scales, splits and
@@ -166,7 +179,7 @@ gru_layer_f16x3(const GruF16Params p) {
             r.lo = seam_src[((size_t)t * 4) * 2 * 64 + 64];
         }
     };
-    auto commit = [&](const XF& r) {
+    auto commit = [&](const XF& r, int slot) {
         if constexpr (FIRST) {
             if (xl_active) {
                 f32x4 v = r.mel * kMelScale;
@@ -175,12 +188,12 @@ gru_layer_f16x3(const GruF16Params p) {
                 unsigned h0, l0, h1, l1;
                 split2((f32x2){v[0], v[1]}, h0, l0);
                 split2((f32x2){v[2], v[3]}, h1, l1);
-                *reinterpret_cast<uint2*>(xs_hi) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(xs_lo) = make_uint2(l0, l1);
+                *reinterpret_cast<uint2*>(xs_hi + slot * (KX * 2 * 64 * 4)) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(xs_lo + slot * (KX * 2 * 64 * 4)) = make_uint2(l0, l1);
             }
         } else {
-            xsb[(w * 2 + 0) * 64 + lane] = r.hi;
-            xsb[(w * 2 + 1) * 64 + lane] = r.lo;
+            xsb[slot * (KX * 2 * 64) + (w * 2 + 0) * 64 + lane] = r.hi;
+            xsb[slot * (KX * 2 * 64) + (w * 2 + 1) * 64 + lane] = r.lo;
         }
     };
 
@@ -222,78 +235,70 @@ gru_layer_f16x3(const GruF16Params p) {
         fl_a.hi = fl_a.lo = fl_b.hi = fl_b.lo = (u32x4){0u, 0u, 0u, 0u};
         __syncthreads();              // LDS tables / previous group's readers
         fetch(fl_a, 0);
-        commit(fl_a);                 // x(0)
-        fetch(fl_b, 1);               // x(1): committed during frame 0
-        fetch(fl_a, 2);               // x(2): committed during frame 1
+        fetch(fl_b, 1);
+        commit(fl_a, 0);              // x(0) -> slot 0
+        commit(fl_b, 1);              // x(1) -> slot 1
+        fetch(fl_b, 2);               // x(2): committed during frame 0
+        fetch(fl_a, 3);               // x(3): committed during frame 1
         __syncthreads();
 
+        // x-part of gate q for the frame whose input sits in xsb slot `slot`: accumulators start from the bias
+        auto xpart = [&](auto q_, int slot, f32x4 (&m)[2][3], f32x4 (&l)[2][3]) {
+            constexpr int q = decltype(q_)::value;
+            constexpr int place = x_place<KX, FIRST>(q);
+            const u32x4* xs = xsb + slot * (KX * 2 * 64);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                m[j][q] = bl[(q * H + (2 * w + j) * 16) / 4 + g];
+                l[j][q] = splat4(0.f);
+            }
+#pragma unroll
+            for (int c = 0; c < KX; ++c) {
+                const f16x8 Bh = as_f16x8(xs[(c * 2 + 0) * 64 + lane]), Bl = as_f16x8(xs[(c * 2 + 1) * 64 + lane]);
+                f16x8 whi[2], wlo[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (place == kInLds) {
+                        whi[j] = as_f16x8(wul[(((w * 2 + j) * KX + c) * 2 + 0) * 64 + lane]);
+                        wlo[j] = as_f16x8(wul[(((w * 2 + j) * KX + c) * 2 + 1) * 64 + lane]);
+                    } else {
+                        whi[j] = wx[j][q][c][0];
+                        wlo[j] = wx[j][q][c][1];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) m[j][q] = mfma_f16(whi[j], Bh, m[j][q]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) l[j][q] = mfma_f16(wlo[j], Bh, l[j][q]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) l[j][q] = mfma_f16(whi[j], Bl, l[j][q]);
+            }
+        };
+        // the frame loop is software-pipelined: iteration t finds bias + x-part(t) in (nm, nl) and computes x-part(t+1), which
+        // depends on nothing of the recurrence, beside the activation arithmetic -- matrix pipe and VALU are separate units
+        f32x4 nm[2][3], nl[2][3];
+        static_for<0, 3>([&](auto q_) { xpart(q_, 0, nm, nl); });
+
         auto frame = [&](int t, XF& fl_commit) {
-            // ---------------- phase 1: x-part of all three gates, recurrent part of r and u ----------------
             f32x4 am[2][3], al[2][3];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    am[j][q] = bl[(q * H + (2 * w + j) * 16) / 4 + g];
-                    al[j][q] = splat4(0.f);
-                }
-            mfma_prefence(am[0][0], am[0][1], am[0][2], am[1][0]);
-            mfma_prefence(am[1][1], am[1][2], al[0][0], al[0][1]);
-            mfma_prefence(al[0][2], al[1][0], al[1][1], al[1][2]);
-#pragma unroll
-            for (int c = 0; c < KX; ++c) {
-                const f16x8 Bh = as_f16x8(xsb[(c * 2 + 0) * 64 + lane]), Bl = as_f16x8(xsb[(c * 2 + 1) * 64 + lane]);
-                static_for<0, 3>([&](auto q_) {
-                    constexpr int q = decltype(q_)::value;
-                    constexpr int place = x_place<KX, FIRST>(q);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if constexpr (place == kInAgpr) {
-                            KWS_MFMA_F16_A(am[j][q], wx[j][q][c][0], Bh);
-                        } else if constexpr (place == kInVgpr) {
-                            am[j][q] = mfma_f16(wx[j][q][c][0], Bh, am[j][q]);
-                        } else {
-                            const f16x8 whi = as_f16x8(wul[(((w * 2 + j) * KX + c) * 2 + 0) * 64 + lane]);
-                            const f16x8 wlo = as_f16x8(wul[(((w * 2 + j) * KX + c) * 2 + 1) * 64 + lane]);
-                            am[j][q] = mfma_f16(whi, Bh, am[j][q]);
-                            al[j][q] = mfma_f16(wlo, Bh, al[j][q]);
-                            al[j][q] = mfma_f16(whi, Bl, al[j][q]);
-                        }
-                    }
-                });
-                static_for<0, 3>([&](auto q_) {
-                    constexpr int q = decltype(q_)::value;
-                    constexpr int place = x_place<KX, FIRST>(q);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if constexpr (place == kInAgpr) KWS_MFMA_F16_A(al[j][q], wx[j][q][c][1], Bh);
-                        else if constexpr (place == kInVgpr) al[j][q] = mfma_f16(wx[j][q][c][1], Bh, al[j][q]);
-                    }
-                });
-                static_for<0, 3>([&](auto q_) {
-                    constexpr int q = decltype(q_)::value;
-                    constexpr int place = x_place<KX, FIRST>(q);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if constexpr (place == kInAgpr) KWS_MFMA_F16_A(al[j][q], wx[j][q][c][0], Bl);
-                        else if constexpr (place == kInVgpr) al[j][q] = mfma_f16(wx[j][q][c][0], Bl, al[j][q]);
-                    }
-                });
-            }
-            mfma_prefence(am[0][0], am[0][1], am[1][0], am[1][1]);
-            mfma_prefence(al[0][0], al[0][1], al[1][0], al[1][1]);
+                for (int q = 0; q < 3; ++q) { am[j][q] = nm[j][q]; al[j][q] = nl[j][q]; }
+            const int nslot = (t + 1) & 1;
+            // ---------------- recurrent part of r and u ----------------
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f16x8 Bh = as_f16x8(hb[(m * 2 + 0) * 64 + lane]), Bl = as_f16x8(hb[(m * 2 + 1) * 64 + lane]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { KWS_MFMA_F16_A(am[j][0], wh[j][0][m][0], Bh); KWS_MFMA_F16_A(am[j][1], wh[j][1][m][0], Bh); }
+                for (int j = 0; j < 2; ++j) { am[j][0] = mfma_f16(wh[j][0][m][0], Bh, am[j][0]); am[j][1] = mfma_f16(wh[j][1][m][0], Bh, am[j][1]); }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { KWS_MFMA_F16_A(al[j][0], wh[j][0][m][1], Bh); KWS_MFMA_F16_A(al[j][1], wh[j][1][m][1], Bh); }
+                for (int j = 0; j < 2; ++j) { al[j][0] = mfma_f16(wh[j][0][m][1], Bh, al[j][0]); al[j][1] = mfma_f16(wh[j][1][m][1], Bh, al[j][1]); }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { KWS_MFMA_F16_A(al[j][0], wh[j][0][m][0], Bl); KWS_MFMA_F16_A(al[j][1], wh[j][1][m][0], Bl); }
+                for (int j = 0; j < 2; ++j) { al[j][0] = mfma_f16(wh[j][0][m][0], Bl, al[j][0]); al[j][1] = mfma_f16(wh[j][1][m][0], Bl, al[j][1]); }
             }
-            mfma_fence(am[0][0], am[0][1], am[1][0], am[1][1]);
-            mfma_fence(al[0][0], al[0][1], al[1][0], al[1][1]);
+            region_fence();
+            // ---------------- r, r (.) h -> LDS; beside it the next frame's x-part of r and u ----------------
             f32x4 u[2], rh[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -310,6 +315,23 @@ gru_layer_f16x3(const GruF16Params p) {
                 rhb[(w * 2 + 0) * 64 + lane] = hi;
                 rhb[(w * 2 + 1) * 64 + lane] = lo;
             }
+            xpart(std::integral_constant<int, 0>{}, nslot, nm, nl);
+            xpart(std::integral_constant<int, 1>{}, nslot, nm, nl);
+            interleave<12 * KX, 1, 3>();      // 12 KX matrix instructions beside the ~70 VALU instructions of the r path
+            region_fence();
+            lds_barrier();            // #1: r (.) h visible; hb fully consumed
+            region_fence();
+            // ---------------- candidate (recurrent part) with the u sigmoid in its shadow ----------------
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f16x8 Bh = as_f16x8(rhb[(m * 2 + 0) * 64 + lane]), Bl = as_f16x8(rhb[(m * 2 + 1) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) am[j][2] = mfma_f16(wh[j][2][m][0], Bh, am[j][2]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) al[j][2] = mfma_f16(wh[j][2][m][1], Bh, al[j][2]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) al[j][2] = mfma_f16(wh[j][2][m][0], Bl, al[j][2]);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x4 pre = combine(am[j][1], al[j][1]);
@@ -317,20 +339,9 @@ gru_layer_f16x3(const GruF16Params p) {
                 const f32x2 u_hi = sigmoid2((f32x2){pre[2], pre[3]});
                 u[j] = (f32x4){u_lo.x, u_lo.y, u_hi.x, u_hi.y};
             }
-            lds_barrier();            // #1: r (.) h visible; hb and xsb fully consumed
-            // ---------------- phase 2: candidate, state update, hand-over ----------------
-            mfma_prefence(am[0][2], am[1][2], al[0][2], al[1][2]);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f16x8 Bh = as_f16x8(rhb[(m * 2 + 0) * 64 + lane]), Bl = as_f16x8(rhb[(m * 2 + 1) * 64 + lane]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) KWS_MFMA_F16_A(am[j][2], wh[j][2][m][0], Bh);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) KWS_MFMA_F16_A(al[j][2], wh[j][2][m][1], Bh);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) KWS_MFMA_F16_A(al[j][2], wh[j][2][m][0], Bl);
-            }
-            mfma_fence(am[0][2], am[1][2], al[0][2], al[1][2]);
+            interleave<24, 1, 1>();
+            region_fence();
+            // ---------------- state update, hand-over; beside it the next frame's x-part of c ----------------
             const unsigned live = t < len_s ? 0xffffffffu : 0u;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -349,6 +360,7 @@ gru_layer_f16x3(const GruF16Params p) {
             split8(hreg[0], hreg[1], hhi, hlo);
             hb[(w * 2 + 0) * 64 + lane] = hhi;
             hb[(w * 2 + 1) * 64 + lane] = hlo;
+            xpart(std::integral_constant<int, 2>{}, nslot, nm, nl);
             // the layer's OUTPUT row is zero past seq_len (dynamic_rnn), its state is copied through
 #pragma unroll
             for (int e = 0; e < 4; ++e) { hhi[e] &= live; hlo[e] &= live; }
@@ -356,19 +368,21 @@ gru_layer_f16x3(const GruF16Params p) {
                 seam_dst[((size_t)t * 4) * 2 * 64] = hhi;
                 seam_dst[((size_t)t * 4) * 2 * 64 + 64] = hlo;
             }
-            commit(fl_commit);        // x(t+1)
-            fetch(fl_commit, t + 3);
+            commit(fl_commit, t & 1);        // x(t+2): its slot was last read during frame t-1
+            fetch(fl_commit, t + 4);
             if constexpr (LAST) {
                 // dense: this wave's 32 units are exactly k-chunk w of Wfc^T
                 f32x4 fm = bfc4, fl = splat4(0.f);
-                asm volatile("s_nop 3" : "+v"(hhi), "+v"(hlo), "+v"(fm), "+v"(fl));      // VALU-written operands -> MFMA distance
                 fm = mfma_f16(wfc[0], as_f16x8(hhi), fm);
                 fl = mfma_f16(wfc[1], as_f16x8(hhi), fl);
                 fl = mfma_f16(wfc[0], as_f16x8(hlo), fl);
                 const f32x4 accf = combine(fm, fl);
                 if (g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
             }
-            lds_barrier();            // #2: h(t), x(t+1), the partial logits visible
+            interleave<6 * KX, 1, 4>();
+            region_fence();
+            lds_barrier();            // #2: h(t), x(t+2), the partial logits visible
+            region_fence();
             if constexpr (LAST) {
                 if (w == (t & 3)) epilogue_fold(epi, t, lane);
                 if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
@@ -378,7 +392,7 @@ gru_layer_f16x3(const GruF16Params p) {
                 }
             }
         };
-        // fl_b holds x(t+1) on even frames, fl_a on odd ones
+        // fl_b holds x(t+2) on even frames, fl_a on odd ones
         for (int t = 0; t < T; t += 2) {
             frame(t, fl_b);
             if (t + 1 < T) frame(t + 1, fl_a);
