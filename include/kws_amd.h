@@ -72,7 +72,7 @@ enum { KWS_FP32 = 0, KWS_BF16 = 1, KWS_INT8 = 2,
        /* fp32 results on the fp16 matrix pipe: every matmul operand split into two fp16 pieces (22 mantissa bits), three
           v_mfma_f32_16x16x32_f16 per product, fp32 accumulation, activations and state (csrc/gru_f16x3.hip).  Meets the
           fp32 path's tolerance (logits within 1e-4 of the reference semantics; observed ~3e-6) at ~2.5x its throughput;
-          it is NOT bit-identical to KWS_FP32.  hidden = 128, n_mel % 4 == 0 and <= 64, any num_layers; |weights| < 128. */
+          it is NOT bit-identical to KWS_FP32.  hidden = 128, n_mel % 4 == 0 and <= 64, any num_layers; |weights| < 64. */
        KWS_F16X3 = 3 };
 
 typedef struct kws_model* kws_handle;

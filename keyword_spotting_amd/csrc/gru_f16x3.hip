@@ -6,20 +6,34 @@
 //     v = hi + 2^-11 lo,   hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (both round-to-nearest-even),
 // weights once at kws_create, activations on the fly (6 VALU instructions per register pair: v_cvt_pk_f16_f32,
 // 2 x v_cvt_f32_f16, v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32).  A product then needs THREE v_mfma_f32_16x16x32_f16
-// instead of eight v_mfma_f32_16x16x4_f32 of twice the duration (48 matrix-pipe cycles per 32 k instead of 256):
+// instead of eight v_mfma_f32_16x16x4_f32 of twice the duration (~51 matrix-pipe cycles per 32 k instead of 256):
 //     main += Wh Xh          lo += Wl Xh + Wh Xl          result = main + 2^-11 lo        (fp32 accumulators)
 // fp16 x fp16 products are exact in fp32; the dropped term Wl Xl 2^-22 is below fp32's own rounding of the product.  The
 // 2^11 scale keeps every lo operand in fp16's normal range (no reliance on how the matrix pipe treats subnormals).  bf16
 // splits would need 3 + 3 pieces and six products for the same 24 bits; fp16's 11-bit pieces need two and three.
-// Range: |hidden| <= 1; weights must be < 32768 in magnitude (kws_create checks); mel is pre-scaled by 2^-8 (and the
+// Range: |hidden| <= 1; weights must be < 64 in magnitude (kws_create checks); mel is pre-scaled by 2^-8 (and the
 // x-part weights of the first layer by 2^8, both exact), so |mel| up to 1.6e7 is represented and larger values saturate.
 //
 // Weights are 4 bytes each again (hi + lo), so residency is the fp32 kernels': ONE LAYER per launch, the layers meet
 // through a seam in HBM -- here already split, in B-operand order, so the layer above reads its input ready to use.
 // One workgroup = 4 waves = 16 streams, wave w owns units [32w, 32w+32) of r, u, c and h' (two 16x16 tiles); the K
 // permutation is gru_bf16.hip's: the wave's two C tiles, split and packed, ARE chunk w of the next B operand.
-//   recurrent operands (48 per wave) + candidate x-part (<= 16)      AGPRs, fed to the MFMA directly ("a" constraint)
-//   gate x-part                                                      first layer: AGPR/VGPR; above: r in VGPRs, u in LDS
+//   recurrent operands (48 per wave) + candidate x-part (<= 16)      AGPRs (64 operands = all 256)
+//   gate x-part            first layer: AGPR / VGPR; above: 4 operands in VGPRs, 28 streamed from LDS through two
+//                          4-operand register sets
+//
+// The frame loop is a static schedule.  Per frame a wave issues 147 (upper layers) / 111 (first layer) MFMAs of ~17
+// cycles and ~180 VALU instructions; an MFMA runs in the matrix pipe while the wave issues VALU work of its own, but issue
+// is in order, so the two only overlap when they ALTERNATE in the instruction stream.  The recurrence fixes a critical
+// chain  gates_h MFMAs -> r sigmoid -> r(.)h split -> LDS -> barrier -> cand_h MFMAs -> tanh, update, split -> LDS ->
+// barrier;  the next frame's x-part (72 / 36 MFMAs, independent of the recurrence) is the filler that is woven, one MFMA
+// per three VALU instructions, into the two activation phases and into the LDS round trips behind the barriers, and the u
+// sigmoid rides under the candidate MFMAs.  The weave is written out below with compile-time indices (streams G, C, X of
+// MFMAs; R, U, Cc of single VALU instructions) and pinned with sched_barrier(0) after every element; the compiler still
+// allocates registers, inserts the waitcnts and sees every hazard (builtin MFMAs only: with MFMA results in VGPRs --
+// csrc/Makefile builds this file with -amdgpu-mfma-vgpr-form, as gru_bf16.hip -- hipcc feeds operands pinned into AGPRs
+// ("+a" at load time) to the builtin directly, no v_accvgpr_read copies; checked in the ISA).
+#include <cstdio>
 #include <cstdlib>
 
 #include "gru_device.h"
@@ -40,11 +54,6 @@ __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-// Resident operands are pinned into AGPRs once (asm "+a" at load time); with MFMA results in VGPRs (csrc/Makefile builds this
-// file with -amdgpu-mfma-vgpr-form, as gru_bf16.hip) hipcc then feeds the BUILTIN MFMA straight from the "a" registers -- no
-// v_accvgpr_read copies (checked in the ISA) -- and, unlike inline-asm MFMAs, it sees every hazard and can interleave the
-// matrix instructions with the activation arithmetic, which is what the frame loop below is arranged for.
-
 __device__ __forceinline__ void split2(f32x2 x, unsigned& hi, unsigned& lo) {
     const f16x2 h = __builtin_convertvector(x, f16x2);
     const f32x2 r = (x - __builtin_convertvector(h, f32x2)) * kLoScale;
@@ -64,43 +73,81 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi
 }
 __device__ __forceinline__ f32x4 combine(const f32x4& m, const f32x4& l) { return m + l * kLoInv; }
 
-// Scheduling regions.  sched_barrier(0): nothing crosses.  interleave<N, M, V>: N times {M matrix instructions, then V VALU
-// instructions} for the instructions of the enclosing region, in dependency order -- an MFMA occupies the matrix pipe for
-// ~17 cycles during which the wave may issue VALU work of its own, but only when the two alternate in the stream (in-order issue).
-__device__ __forceinline__ void region_fence() { __builtin_amdgcn_sched_barrier(0); }
-template <int N, int M, int V>
-__device__ __forceinline__ void interleave() {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
-    }
+// nothing is scheduled across this point: the weave below stays as written
+__device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
+
+// NA elements of stream a and NB of stream b, evenly merged, each pinned in place; the streams' own indices start at A0 /
+// B0.  fa / fb take std::integral_constant<int, index>.
+template <int NA, int A0, int NB, int B0, class FA, class FB>
+__device__ __forceinline__ void zip(FA&& fa, FB&& fb) {
+    static_for<0, NA + NB>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int b_before = (int)((long long)i * NB / (NA + NB)), b_after = (int)((long long)(i + 1) * NB / (NA + NB));
+        if constexpr (b_after > b_before) fb(std::integral_constant<int, B0 + b_before>{});
+        else fa(std::integral_constant<int, A0 + (i - b_before)>{});
+        pin();
+    });
+}
+template <int N, int I0, class F>
+__device__ __forceinline__ void run(F&& f) {
+    static_for<0, N>([&](auto i_) { f(std::integral_constant<int, I0 + decltype(i_)::value>{}); pin(); });
 }
 
 enum { kInAgpr = 0, kInVgpr = 1, kInLds = 2 };
-// where gate q's x-part operands of a layer with KX x-chunks live
+// where the x-part operands of gate q, chunk c live
 template <int KX, bool FIRST>
-constexpr int x_place(int q) {
+constexpr int x_place(int q, int c) {
     if (q == 2) return kInAgpr;                                  // candidate: 4 KX <= 16 operands
     if (FIRST) return (q == 0 || KX == 1) ? kInAgpr : kInVgpr;   // 48 + 12 KX <= 64 AGPR operands only for KX = 1
-    return q == 0 ? kInVgpr : kInLds;
+    return (q == 0 && c < 1) ? kInVgpr : kInLds;
 }
+// LDS-resident (gate, chunk) groups in the order the x stream meets them (chunk-major, r before u): index or -1
+template <int KX, bool FIRST>
+constexpr int lds_group(int q, int c) {
+    if (x_place<KX, FIRST>(q, c) != kInLds) return -1;
+    int k = 0;
+    for (int cc = 0; cc < KX; ++cc)
+        for (int qq = 0; qq < 2; ++qq) {
+            if (cc == c && qq == q) return k;
+            if (x_place<KX, FIRST>(qq, cc) == kInLds) ++k;
+        }
+    return -1;
+}
+template <int KX, bool FIRST>
+constexpr int lds_groups() {
+    int k = 0;
+    for (int cc = 0; cc < KX; ++cc)
+        for (int qq = 0; qq < 2; ++qq)
+            if (x_place<KX, FIRST>(qq, cc) == kInLds) ++k;
+    return k;
+}
+
+#ifdef KWS_F16_TIMING       // tools/build_variant.sh timing -DKWS_F16_TIMING; tools/exp_f16_timing.py: cycles per phase of the frame loop
+__device__ long long* g_timing = nullptr;
+#define KWS_STAMP(i) do { const long long now_ = __builtin_readcyclecounter(); tsum[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define KWS_STAMP(i) do {} while (0)
+#endif
 
 }  // namespace
 
 size_t gru_f16x3_lds_bytes(int kx, bool first, bool last) {
     size_t n = 2 * 4 * 2 * 64 * 16;                      // hb, rhb
-    n += (size_t)2 * kx * 2 * 64 * 16;                   // xsb, two slots
-    if (!first) n += (size_t)4 * 16 * 64 * 16;           // u-gate x-part operands, per wave
-    n += 3 * 128 * 4;                                    // biases
+    n += (size_t)(first ? 3 : 2) * kx * 2 * 64 * 16;     // xsb: three slots in the first layer, two above
+    if (first) n += 512;                                 // dump row for the idle lanes' mel stores
+    if (!first) n += (size_t)4 * 7 * 4 * 64 * 16;        // gate x-part operands streamed from LDS: 7 groups of 4 per wave
+    n += 3 * 128 * 4 + 16 * 4;                           // biases
     if (last) n += kEpilogueLdsBytes;
     return n;
 }
 
-template <int KX, bool FIRST, bool LAST>
+template <int KX, bool FIRST, bool LAST, bool MASKED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gru_layer_f16x3(const GruF16Params p) {
     constexpr int H = 128, KC = KX + 4;
+    constexpr int NG = lds_groups<KX, FIRST>();          // LDS-resident operand groups per wave (0 or 7)
+    constexpr int NX = 18 * KX;                          // MFMAs of one frame's x-part
+    static_assert(FIRST ? NG == 0 : NG == 7, "gru_f16x3_lds_bytes assumes 7 streamed groups above the first layer");
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, g = lane >> 4, s = lane & 15;
@@ -110,21 +157,21 @@ gru_layer_f16x3(const GruF16Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* hb = reinterpret_cast<u32x4*>(smem);              // [4 chunks][hi|lo][64]   h_{t-1}
     u32x4* rhb = hb + 4 * 2 * 64;                             // [4][2][64]              r (.) h_{t-1}
-    u32x4* xsb = rhb + 4 * 2 * 64;                            // [2 slots][KX][2][64]    input of frames t+1, t+2 (ping-pong)
-    u32x4* wul = xsb + 2 * KX * 2 * 64;                         // !FIRST: [4 waves][2 tiles][KX][2][64]  u-gate x-part
-    float* biasl = reinterpret_cast<float*>(wul + (FIRST ? 0 : 4 * 2 * KX * 2 * 64));   // [3][128]
-    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * H));      // LAST only
+    constexpr int NS = FIRST ? 3 : 2;                         // xsb slots: frame t's input sits in slot t % NS
+    u32x4* xsb = rhb + 4 * 2 * 64;                            // [NS slots][KX][2][64]
+    u32x4* wul = xsb + NS * KX * 2 * 64 + (FIRST ? 32 : 0);                      // !FIRST: [4 waves][NG groups][tile j][hi|lo][64]
+    float* biasl = reinterpret_cast<float*>(wul + 4 * NG * 4 * 64);    // [3][128] + [16] class bias
+    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * H + 16));      // LAST only
 
     // ---- operands: [tile j][gate q][chunk][hi|lo]; table p.w is [8 tiles][3][KC][2][64 lanes] x 16 B, x chunks first ----
-    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w);
-    auto wload = [&](int j, int q, int c, int hl) { return as_f16x8(wt[((((2 * w + j) * 3 + q) * KC + c) * 2 + hl) * 64 + lane]); };
+    const u32x4* wt_tab = reinterpret_cast<const u32x4*>(p.w);
+    auto wload = [&](int j, int q, int c, int hl) { return as_f16x8(wt_tab[((((2 * w + j) * 3 + q) * KC + c) * 2 + hl) * 64 + lane]); };
     f16x8 wh[2][3][4][2];          // recurrent part: AGPRs
     f16x8 wx[2][3][KX][2];         // x-part: by x_place
 #pragma unroll
     for (int j = 0; j < 2; ++j)
         static_for<0, 3>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
-            constexpr int place = x_place<KX, FIRST>(q);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -132,51 +179,57 @@ gru_layer_f16x3(const GruF16Params p) {
                     wh[j][q][m][hl] = wload(j, q, KX + m, hl);
                     asm volatile("" : "+a"(wh[j][q][m][hl]));
                 }
-#pragma unroll
-            for (int c = 0; c < KX; ++c)
+            static_for<0, KX>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                constexpr int place = x_place<KX, FIRST>(q, c);
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl) {
                     if constexpr (place == kInLds) {
-                        wul[(((w * 2 + j) * KX + c) * 2 + hl) * 64 + lane] = wt[((((2 * w + j) * 3 + q) * KC + c) * 2 + hl) * 64 + lane];
+                        constexpr int k = lds_group<KX, FIRST>(q, c);
+                        wul[((w * NG + k) * 4 + j * 2 + hl) * 64 + lane] = wt_tab[((((2 * w + j) * 3 + q) * KC + c) * 2 + hl) * 64 + lane];
                     } else {
                         wx[j][q][c][hl] = wload(j, q, c, hl);
                         if constexpr (place == kInAgpr) asm volatile("" : "+a"(wx[j][q][c][hl]));
                     }
                 }
+            });
         });
-    asm volatile("s_nop 7" ::: "memory");       // v_accvgpr_write -> MFMA SrcA distance
-    f16x8 wfc[2];
-    f32x4 bfc4 = splat4(0.f);
-    if constexpr (LAST) {
-        wfc[0] = as_f16x8(reinterpret_cast<const u32x4*>(p.wfc)[(w * 2 + 0) * 64 + lane]);
-        wfc[1] = as_f16x8(reinterpret_cast<const u32x4*>(p.wfc)[(w * 2 + 1) * 64 + lane]);
-        if (w == 0) bfc4 = ld4(p.bfc + 4 * g);
-    }
-    for (int i = tid; i < 3 * H; i += 256) biasl[i] = p.bias[i];
-    for (int i = tid; i < 2 * KX * 2 * 64; i += 256) xsb[i] = (u32x4){0u, 0u, 0u, 0u};
+    // LAST: the projection's operands (this wave's k-chunk of Wfc^T, hi and lo) are re-read every frame (2 KiB per wave, L1/L2
+    // hits, requested a phase ahead): eight registers the upper layers do not have to spare
+    const u32x4* wfc_src = reinterpret_cast<const u32x4*>(p.wfc) + (w * 2) * 64;        // uniform
+    // kws_create folded the exponent scales into the weights (gates: -log2 e, candidate: 2 log2 e), so a pre-activation IS the
+    // argument of exp2; the biases get the same factors here
+    for (int i = tid; i < 3 * H; i += 256) biasl[i] = p.bias[i] * (i < 2 * H ? -kLog2e : 2.0f * kLog2e);
+    if (LAST && tid < 16) biasl[3 * H + tid] = w == 0 ? p.bfc[tid] : 0.f;       // the class bias enters through wave 0's partial logits
+    for (int i = tid; i < NS * KX * 2 * 64; i += 256) xsb[i] = (u32x4){0u, 0u, 0u, 0u};
     const f32x4* bl = reinterpret_cast<const f32x4*>(biasl);
+    const u32x4* wul_w = wul + w * (NG * 4 * 64) + lane;
 
     // ---- input fetch: FIRST: wave w brings streams 4w..4w+3 of the mel frame (one dwordx4 per lane), scales, splits and
-    // scatters them into the B-operand image; above: wave w brings chunk w of the seam (hi, lo), already in operand order
+    // scatters them into the B-operand image; above: wave w brings chunk w of the seam (hi, lo), already in operand order.
+    // Every global address is a wave-uniform base (scalar registers) plus a 32-bit lane offset: per-lane 64-bit pointers
+    // would cost this kernel a dozen of the vector registers it does not have.
     const int XQ = FIRST ? p.I / 4 : 1;
     const int xl_row = lane / XQ, xl_q = lane % XQ;
     const bool xl_active = lane < 4 * XQ;
     struct XF { f32x4 mel; u32x4 hi, lo; };
-    const float4* mel_src = nullptr;
-    const u32x4* seam_src = nullptr;
-    unsigned* xs_hi = reinterpret_cast<unsigned*>(xsb) +
-                      ((((xl_q * 4) / 32) * 2 + 0) * 64 + (((xl_q * 4) % 32) / 8) * 16 + (4 * w + xl_row)) * 4 + ((xl_q * 4) % 8) / 2;
-    unsigned* xs_lo = xs_hi + 64 * 4;
+    const float* mel_base = nullptr;       // FIRST: &mel[16 group][0][0], uniform
+    unsigned mel_lane = 0;                 // FIRST: this lane's (row within the group, quarter) offset in floats
+    const u32x4* seam_base = nullptr;      // above: &seam[group][0][chunk w][0][0], uniform
+    const int xs_lane = ((((xl_q * 4) / 32) * 2 + 0) * 64 + (((xl_q * 4) % 32) / 8) * 16 + (4 * w + xl_row)) * 4 + ((xl_q * 4) % 8) / 2;   // dwords
+    unsigned* const xsb_dw = reinterpret_cast<unsigned*>(xsb);
+    const int xs_dump = NS * KX * 2 * 64 * 4 + 2 * lane;      // FIRST: 512 B behind the slots, where idle lanes' stores go
     auto fetch = [&](XF& r, int t_req) {
         const int t = t_req < T ? t_req : T - 1;
         if constexpr (FIRST) {
             if (xl_active) {
-                const float4 v = mel_src[(size_t)t * XQ];
+                const float4 v = *reinterpret_cast<const float4*>(mel_base + (size_t)t * p.I + mel_lane);
                 r.mel = (f32x4){v.x, v.y, v.z, v.w};
             }
         } else {
-            r.hi = seam_src[((size_t)t * 4) * 2 * 64];
-            r.lo = seam_src[((size_t)t * 4) * 2 * 64 + 64];
+            const u32x4* src = seam_base + (size_t)t * (4 * 2 * 64);
+            r.hi = src[lane];
+            r.lo = src[64 + lane];
         }
     };
     auto commit = [&](const XF& r, int slot) {
@@ -188,14 +241,19 @@ gru_layer_f16x3(const GruF16Params p) {
                 unsigned h0, l0, h1, l1;
                 split2((f32x2){v[0], v[1]}, h0, l0);
                 split2((f32x2){v[2], v[3]}, h1, l1);
-                *reinterpret_cast<uint2*>(xs_hi + slot * (KX * 2 * 64 * 4)) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(xs_lo + slot * (KX * 2 * 64 * 4)) = make_uint2(l0, l1);
+                *reinterpret_cast<uint2*>(xsb_dw + slot * (KX * 2 * 64 * 4) + xs_lane) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(xsb_dw + slot * (KX * 2 * 64 * 4) + 64 * 4 + xs_lane) = make_uint2(l0, l1);
             }
         } else {
             xsb[slot * (KX * 2 * 64) + (w * 2 + 0) * 64 + lane] = r.hi;
             xsb[slot * (KX * 2 * 64) + (w * 2 + 1) * 64 + lane] = r.lo;
         }
     };
+
+    // The activation streams are single instructions; a 32-bit literal doubles an instruction's size (8 bytes), and a lone
+    // wave per SIMD is fed instructions at a limited rate, so the constants live in scalar registers (VOP2 encodings, 4 bytes).
+    float cLoInv = kLoInv, cLoScale = kLoScale, cNegLoScale = -kLoScale, cNegTwo = -2.0f;
+    asm volatile("" : "+s"(cLoInv), "+s"(cLoScale), "+s"(cNegLoScale), "+s"(cNegTwo));
 
     for (int group = blockIdx.x; group < n_groups; group += gridDim.x) {
         const int b_raw = group * kStreamsPerGroup + s;
@@ -222,181 +280,327 @@ gru_layer_f16x3(const GruF16Params p) {
             }
         }
         if constexpr (FIRST) {
-            const int xl_b = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1);
-            mel_src = reinterpret_cast<const float4*>(p.x_mel + (size_t)xl_b * T * p.I) + xl_q;
+            const int row = min(group * kStreamsPerGroup + 4 * w + (xl_active ? xl_row : 0), p.B - 1) - group * kStreamsPerGroup;
+            mel_base = p.x_mel + (size_t)group * kStreamsPerGroup * T * p.I;
+            mel_lane = (unsigned)row * (unsigned)(T * p.I) + (unsigned)xl_q * 4u;
         } else {
-            seam_src = reinterpret_cast<const u32x4*>(p.x_prev) + ((size_t)group * T * 4 + w) * 2 * 64 + lane;
+            seam_base = reinterpret_cast<const u32x4*>(p.x_prev) + ((size_t)group * T * 4 + w) * 2 * 64;
         }
-        u32x4* seam_dst = nullptr;
-        if constexpr (!LAST) seam_dst = reinterpret_cast<u32x4*>(p.h_out) + ((size_t)group * T * 4 + w) * 2 * 64 + lane;
+        u32x4* seam_out = nullptr;       // !LAST: &seam[group][0][chunk w][0][0], uniform
+        if constexpr (!LAST) seam_out = reinterpret_cast<u32x4*>(p.h_out) + ((size_t)group * T * 4 + w) * 2 * 64;
 
-        XF fl_a, fl_b;
-        fl_a.mel = fl_b.mel = splat4(0.f);
-        fl_a.hi = fl_a.lo = fl_b.hi = fl_b.lo = (u32x4){0u, 0u, 0u, 0u};
+        XF fl;
+        fl.mel = splat4(0.f);
+        fl.hi = fl.lo = (u32x4){0u, 0u, 0u, 0u};
         __syncthreads();              // LDS tables / previous group's readers
-        fetch(fl_a, 0);
-        fetch(fl_b, 1);
-        commit(fl_a, 0);              // x(0) -> slot 0
-        commit(fl_b, 1);              // x(1) -> slot 1
-        fetch(fl_b, 2);               // x(2): committed during frame 0
-        fetch(fl_a, 3);               // x(3): committed during frame 1
+        fetch(fl, 0);
+        commit(fl, 0);                // x(0) -> slot 0
+        fetch(fl, 1);
+        commit(fl, 1);                // x(1) -> slot 1
+        fetch(fl, 2);                 // x(2): committed during frame 0
         __syncthreads();
 
-        // x-part of gate q for the frame whose input sits in xsb slot `slot`: accumulators start from the bias
-        auto xpart = [&](auto q_, int slot, f32x4 (&m)[2][3], f32x4 (&l)[2][3]) {
-            constexpr int q = decltype(q_)::value;
-            constexpr int place = x_place<KX, FIRST>(q);
-            const u32x4* xs = xsb + slot * (KX * 2 * 64);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                m[j][q] = bl[(q * H + (2 * w + j) * 16) / 4 + g];
-                l[j][q] = splat4(0.f);
-            }
-#pragma unroll
-            for (int c = 0; c < KX; ++c) {
-                const f16x8 Bh = as_f16x8(xs[(c * 2 + 0) * 64 + lane]), Bl = as_f16x8(xs[(c * 2 + 1) * 64 + lane]);
-                f16x8 whi[2], wlo[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (place == kInLds) {
-                        whi[j] = as_f16x8(wul[(((w * 2 + j) * KX + c) * 2 + 0) * 64 + lane]);
-                        wlo[j] = as_f16x8(wul[(((w * 2 + j) * KX + c) * 2 + 1) * 64 + lane]);
-                    } else {
-                        whi[j] = wx[j][q][c][0];
-                        wlo[j] = wx[j][q][c][1];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) m[j][q] = mfma_f16(whi[j], Bh, m[j][q]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) l[j][q] = mfma_f16(wlo[j], Bh, l[j][q]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) l[j][q] = mfma_f16(whi[j], Bl, l[j][q]);
-            }
-        };
-        // the frame loop is software-pipelined: iteration t finds bias + x-part(t) in (nm, nl) and computes x-part(t+1), which
-        // depends on nothing of the recurrence, beside the activation arithmetic -- matrix pipe and VALU are separate units
-        f32x4 nm[2][3], nl[2][3];
-        static_for<0, 3>([&](auto q_) { xpart(q_, 0, nm, nl); });
-
-        auto frame = [&](int t, XF& fl_commit) {
-            f32x4 am[2][3], al[2][3];
+        // ---- the streams ------------------------------------------------------------------------------------------
+        // accumulators of two frames in flight: set t & 1 belongs to frame t.  [set][tile j][gate q]
+        f32x4 am[2][2][3], al[2][2][3];
+        // X: the x-part of the frame with parity PN (input in the xsb slot xs_ptr[PN] points at), 18 MFMAs per chunk: gate
+        // r, u, c; per gate the three products over the two tiles.  Operands streamed from LDS arrive through two 4-operand
+        // register sets, the input chunks through two (hi, lo) pairs; element i also issues the loads that elements
+        // ~12..18 further on need.
+        f16x8 xb[2][2], wtmp[2][2][2];
+        int xs_off[2] = {lane, lane};            // element offset of the slot the x stream of each parity reads, + lane
+        auto xbegin = [&](auto pn_, int slot) {   // accumulators from the bias, first two chunks and operand groups on their way
+            constexpr int PN = decltype(pn_)::value;
+            xs_off[PN] = slot * (KX * 2 * 64) + lane;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { am[j][q] = nm[j][q]; al[j][q] = nl[j][q]; }
-            const int nslot = (t + 1) & 1;
-            // ---------------- recurrent part of r and u ----------------
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f16x8 Bh = as_f16x8(hb[(m * 2 + 0) * 64 + lane]), Bl = as_f16x8(hb[(m * 2 + 1) * 64 + lane]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { am[j][0] = mfma_f16(wh[j][0][m][0], Bh, am[j][0]); am[j][1] = mfma_f16(wh[j][1][m][0], Bh, am[j][1]); }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { al[j][0] = mfma_f16(wh[j][0][m][1], Bh, al[j][0]); al[j][1] = mfma_f16(wh[j][1][m][1], Bh, al[j][1]); }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { al[j][0] = mfma_f16(wh[j][0][m][0], Bl, al[j][0]); al[j][1] = mfma_f16(wh[j][1][m][0], Bl, al[j][1]); }
-            }
-            region_fence();
-            // ---------------- r, r (.) h -> LDS; beside it the next frame's x-part of r and u ----------------
-            f32x4 u[2], rh[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 pre = combine(am[j][0], al[j][0]);
-                const f32x2 r_lo = sigmoid2((f32x2){pre[0], pre[1]});
-                const f32x2 r_hi = sigmoid2((f32x2){pre[2], pre[3]});
-                const f32x2 a = r_lo * (f32x2){hreg[j][0], hreg[j][1]};
-                const f32x2 c2 = r_hi * (f32x2){hreg[j][2], hreg[j][3]};
-                rh[j] = (f32x4){a.x, a.y, c2.x, c2.y};
-            }
-            {
-                u32x4 hi, lo;
-                split8(rh[0], rh[1], hi, lo);
-                rhb[(w * 2 + 0) * 64 + lane] = hi;
-                rhb[(w * 2 + 1) * 64 + lane] = lo;
-            }
-            xpart(std::integral_constant<int, 0>{}, nslot, nm, nl);
-            xpart(std::integral_constant<int, 1>{}, nslot, nm, nl);
-            interleave<12 * KX, 1, 3>();      // 12 KX matrix instructions beside the ~70 VALU instructions of the r path
-            region_fence();
-            lds_barrier();            // #1: r (.) h visible; hb fully consumed
-            region_fence();
-            // ---------------- candidate (recurrent part) with the u sigmoid in its shadow ----------------
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f16x8 Bh = as_f16x8(rhb[(m * 2 + 0) * 64 + lane]), Bl = as_f16x8(rhb[(m * 2 + 1) * 64 + lane]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) am[j][2] = mfma_f16(wh[j][2][m][0], Bh, am[j][2]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) al[j][2] = mfma_f16(wh[j][2][m][1], Bh, al[j][2]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) al[j][2] = mfma_f16(wh[j][2][m][0], Bl, al[j][2]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 pre = combine(am[j][1], al[j][1]);
-                const f32x2 u_lo = sigmoid2((f32x2){pre[0], pre[1]});
-                const f32x2 u_hi = sigmoid2((f32x2){pre[2], pre[3]});
-                u[j] = (f32x4){u_lo.x, u_lo.y, u_hi.x, u_hi.y};
-            }
-            interleave<24, 1, 1>();
-            region_fence();
-            // ---------------- state update, hand-over; beside it the next frame's x-part of c ----------------
-            const unsigned live = t < len_s ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 pre = combine(am[j][2], al[j][2]);
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f32x2 c = tanh2((f32x2){pre[2 * h2], pre[2 * h2 + 1]});
-                    const f32x2 uu = {u[j][2 * h2], u[j][2 * h2 + 1]};
-                    const f32x2 hh = {hreg[j][2 * h2], hreg[j][2 * h2 + 1]};
-                    const f32x2 hn = (1.0f - uu) * c + uu * hh;
-                    hreg[j][2 * h2] = bitsel(live, hn.x, hh.x);
-                    hreg[j][2 * h2 + 1] = bitsel(live, hn.y, hh.y);
+                for (int q = 0; q < 3; ++q) {
+                    am[PN][j][q] = bl[(q * H + (2 * w + j) * 16) / 4 + g];
+                    al[PN][j][q] = splat4(0.f);
                 }
-            }
-            u32x4 hhi, hlo;
-            split8(hreg[0], hreg[1], hhi, hlo);
-            hb[(w * 2 + 0) * 64 + lane] = hhi;
-            hb[(w * 2 + 1) * 64 + lane] = hlo;
-            xpart(std::integral_constant<int, 2>{}, nslot, nm, nl);
-            // the layer's OUTPUT row is zero past seq_len (dynamic_rnn), its state is copied through
+            static_for<0, (KX < 2 ? KX : 2)>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                xb[c][0] = as_f16x8(xsb[xs_off[PN] + (c * 2 + 0) * 64]);
+                xb[c][1] = as_f16x8(xsb[xs_off[PN] + (c * 2 + 1) * 64]);
+            });
+            static_for<0, (NG < 2 ? NG : 2)>([&](auto k_) {
+                constexpr int k = decltype(k_)::value;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { hhi[e] &= live; hlo[e] &= live; }
-            if constexpr (!LAST) {
-                seam_dst[((size_t)t * 4) * 2 * 64] = hhi;
-                seam_dst[((size_t)t * 4) * 2 * 64 + 64] = hlo;
+                for (int jh = 0; jh < 4; ++jh) wtmp[k][jh >> 1][jh & 1] = as_f16x8(wul_w[(k * 4 + jh) * 64]);
+            });
+        };
+        auto X = [&](auto pn_, auto i_) {
+            constexpr int PN = decltype(pn_)::value, i = decltype(i_)::value;
+            constexpr int c = i / 18, r = i % 18, q = r / 6, sweep = (r % 6) / 2, j = r % 2;
+            constexpr int place = x_place<KX, FIRST>(q, c);
+            constexpr int k = lds_group<KX, FIRST>(q, c);
+            const f16x8 B = xb[c & 1][sweep == 2 ? 1 : 0];
+            f16x8 W;
+            if constexpr (place == kInLds) W = wtmp[k & 1][j][sweep == 1 ? 1 : 0];
+            else W = wx[j][q][c][sweep == 1 ? 1 : 0];
+            if constexpr (sweep == 0) am[PN][j][q] = mfma_f16(W, B, am[PN][j][q]);
+            else al[PN][j][q] = mfma_f16(W, B, al[PN][j][q]);
+            if constexpr (place == kInLds && r % 6 == 5 && k + 2 < NG) {       // this group's register set is free again
+#pragma unroll
+                for (int jh = 0; jh < 4; ++jh) wtmp[k & 1][jh >> 1][jh & 1] = as_f16x8(wul_w[((k + 2) * 4 + jh) * 64]);
             }
-            commit(fl_commit, t & 1);        // x(t+2): its slot was last read during frame t-1
-            fetch(fl_commit, t + 4);
-            if constexpr (LAST) {
-                // dense: this wave's 32 units are exactly k-chunk w of Wfc^T
-                f32x4 fm = bfc4, fl = splat4(0.f);
-                fm = mfma_f16(wfc[0], as_f16x8(hhi), fm);
-                fl = mfma_f16(wfc[1], as_f16x8(hhi), fl);
-                fl = mfma_f16(wfc[0], as_f16x8(hlo), fl);
-                const f32x4 accf = combine(fm, fl);
-                if (g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
-            }
-            interleave<6 * KX, 1, 4>();
-            region_fence();
-            lds_barrier();            // #2: h(t), x(t+2), the partial logits visible
-            region_fence();
-            if constexpr (LAST) {
-                if (w == (t & 3)) epilogue_fold(epi, t, lane);
-                if (((t + 1) & (kRingFrames - 1)) == 0 || t == T - 1) {
-                    const int t0 = t & ~(kRingFrames - 1);
-                    lds_barrier();
-                    epilogue_flush(p.epi, epi, group, t0, t - t0 + 1, w, lane, t == T - 1);
-                }
+            if constexpr (r == 17 && c + 2 < KX) {
+                xb[c & 1][0] = as_f16x8(xsb[xs_off[PN] + ((c + 2) * 2 + 0) * 64]);
+                xb[c & 1][1] = as_f16x8(xsb[xs_off[PN] + ((c + 2) * 2 + 1) * 64]);
             }
         };
-        // fl_b holds x(t+2) on even frames, fl_a on odd ones
-        for (int t = 0; t < T; t += 2) {
-            frame(t, fl_b);
-            if (t + 1 < T) frame(t + 1, fl_a);
+        // G: recurrent part of r and u, 12 MFMAs per chunk of h(t-1); Cm: of the candidate, 6 per chunk of r (.) h.
+        f16x8 hB[2][2];
+        auto hread = [&](const u32x4* src, int m, int buf) {
+            hB[buf][0] = as_f16x8(src[(m * 2 + 0) * 64 + lane]);
+            hB[buf][1] = as_f16x8(src[(m * 2 + 1) * 64 + lane]);
+        };
+        auto G = [&](auto pc_, auto i_) {
+            constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value;
+            constexpr int m = i / 12, r = i % 12, sweep = r / 4, j = (r % 4) / 2, q = r % 2;
+            const f16x8 B = hB[m & 1][sweep == 2 ? 1 : 0];
+            const f16x8 W = wh[j][q][m][sweep == 1 ? 1 : 0];
+            if constexpr (sweep == 0) am[PC][j][q] = mfma_f16(W, B, am[PC][j][q]);
+            else al[PC][j][q] = mfma_f16(W, B, al[PC][j][q]);
+            if constexpr (r == 11 && m + 2 < 4) hread(hb, m + 2, m & 1);
+        };
+        auto Cm = [&](auto pc_, auto i_) {
+            constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value;
+            constexpr int m = i / 6, r = i % 6, sweep = r / 2, j = r % 2;
+            const f16x8 B = hB[m & 1][sweep == 2 ? 1 : 0];
+            const f16x8 W = wh[j][2][m][sweep == 1 ? 1 : 0];
+            if constexpr (sweep == 0) am[PC][j][2] = mfma_f16(W, B, am[PC][j][2]);
+            else al[PC][j][2] = mfma_f16(W, B, al[PC][j][2]);
+            if constexpr (r == 5 && m + 2 < 4) hread(rhb, m + 2, m & 1);
+        };
+        // R, U, Cc: the activation arithmetic, ONE scalar VALU instruction per element (packed fp32 instructions beside MFMAs
+        // are slower than the two scalar ones they replace), the lane's eight values (tile j, row e) in flight side by side so
+        // that no element waits for the one before it: stage-major order.  The fp16 pack stages have four elements.
+        // Split of a value v with hi already packed:  lo16 = fp16(fma(hi16 as f32, -2^11, v * 2^11))  -- v_fma_mixlo/hi_f16 reads
+        // the fp16 half directly and writes the rounded fp16 half in place (bit-identical to the subtract-scale-convert form).
+        float va[8], vb[8], uu[8];
+        unsigned phi[4], plo[4] = {0u, 0u, 0u, 0u};
+        auto mix_lo = [&](auto un_, float m) {
+            constexpr int un = decltype(un_)::value;
+            const unsigned hi = phi[un >> 1];
+            const float nk = cNegLoScale;
+            unsigned d = plo[un >> 1];
+            if constexpr ((un & 1) == 0) asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi), "s"(nk), "v"(m));
+            else asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi), "s"(nk), "v"(m));
+            plo[un >> 1] = d;
+        };
+        auto R = [&](auto pc_, auto i_) {
+            constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value;
+            // stages: 0 fma, 1 exp, 2 add, 3 rcp, 4 mul h | 5 pack hi (4) | 6 scale, 7 lo half
+            constexpr int st = i < 40 ? i / 8 : i < 44 ? 5 : 6 + (i - 44) / 8;
+            constexpr int un = i < 40 ? i % 8 : i < 44 ? i - 40 : (i - 44) % 8;
+            if constexpr (st == 5) phi[un] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){va[2 * un], va[2 * un + 1]}, f16x2));
+            else {
+                constexpr int j = un >> 2, e = un & 3;
+                if constexpr (st == 0) va[un] = __builtin_fmaf(al[PC][j][0][e], cLoInv, am[PC][j][0][e]);
+                else if constexpr (st == 1) va[un] = __builtin_amdgcn_exp2f(va[un]);
+                else if constexpr (st == 2) va[un] = va[un] + 1.0f;
+                else if constexpr (st == 3) va[un] = __builtin_amdgcn_rcpf(va[un]);
+                else if constexpr (st == 4) va[un] = va[un] * hreg[j][e];
+                else if constexpr (st == 6) vb[un] = va[un] * cLoScale;
+                else mix_lo(std::integral_constant<int, un>{}, vb[un]);
+            }
+        };
+        constexpr int NR = 5 * 8 + 4 + 2 * 8;         // 60
+        auto U = [&](auto pc_, auto i_) {
+            constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value, st = i / 8, un = i % 8, j = un >> 2, e = un & 3;
+            if constexpr (st == 0) uu[un] = __builtin_fmaf(al[PC][j][1][e], cLoInv, am[PC][j][1][e]);
+            else if constexpr (st == 1) uu[un] = __builtin_amdgcn_exp2f(uu[un]);
+            else if constexpr (st == 2) uu[un] = uu[un] + 1.0f;
+            else uu[un] = __builtin_amdgcn_rcpf(uu[un]);
+        };
+        constexpr int NU = 4 * 8;                     // 32
+        unsigned live = 0u;
+        constexpr int NCS = MASKED ? 8 : 7;           // elementwise stages of the candidate path before the split
+        auto Cc = [&](auto pc_, auto i_) {
+            constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value;
+            // stages: 0 fma, 1 exp, 2 add, 3 rcp, 4 fma (tanh), 5 sub, 6 fma (update) [, 7 select: MASKED] | pack hi (4) | scale, lo half
+            constexpr int st = i < NCS * 8 ? i / 8 : i < NCS * 8 + 4 ? 100 : 101 + (i - NCS * 8 - 4) / 8;
+            constexpr int un = i < NCS * 8 ? i % 8 : i < NCS * 8 + 4 ? i - NCS * 8 : (i - NCS * 8 - 4) % 8;
+            if constexpr (st == 100) phi[un] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){hreg[un >> 1][2 * (un & 1)], hreg[un >> 1][2 * (un & 1) + 1]}, f16x2));
+            else {
+                constexpr int j = un >> 2, e = un & 3;
+                if constexpr (st == 0) va[un] = __builtin_fmaf(al[PC][j][2][e], cLoInv, am[PC][j][2][e]);
+                else if constexpr (st == 1) va[un] = __builtin_amdgcn_exp2f(va[un]);
+                else if constexpr (st == 2) va[un] = va[un] + 1.0f;
+                else if constexpr (st == 3) va[un] = __builtin_amdgcn_rcpf(va[un]);
+                else if constexpr (st == 4) va[un] = __builtin_fmaf(va[un], cNegTwo, 1.0f);                     // tanh
+                else if constexpr (st == 5) vb[un] = hreg[j][e] - va[un];
+                else if constexpr (st == 6) {
+                    if constexpr (MASKED) va[un] = __builtin_fmaf(uu[un], vb[un], va[un]);                      // c + u (h - c)
+                    else hreg[j][e] = __builtin_fmaf(uu[un], vb[un], va[un]);
+                } else if constexpr (st == 7) hreg[j][e] = bitsel(live, va[un], hreg[j][e]);                  // copy-through past seq_len
+                else if constexpr (st == 101) vb[un] = hreg[j][e] * cLoScale;
+                else mix_lo(std::integral_constant<int, un>{}, vb[un]);
+            }
+        };
+        constexpr int NC = NCS * 8 + 4 + 2 * 8;       // 76 (84 with the mask)
+        // FIRST: the next-but-one mel frame (one dwordx4 per lane, streams 4w..4w+3) -> scaled, clamped, split, scattered into
+        // its xsb slot; 24 scalar VALU elements that ride under the G MFMAs, then the two LDS stores
+        float mv[4], mr[4];
+        unsigned mh[2], ml[2];
+        auto Mq = [&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            // stages: 0 scale (4), 1 clamp (4), 2 pack hi (2), 3 unpack (4), 4 sub (4), 5 mul (4), 6 pack lo (2)
+            constexpr int st = i < 8 ? i / 4 : i < 10 ? 2 : i < 22 ? 3 + (i - 10) / 4 : 6;
+            constexpr int un = i < 8 ? i % 4 : i < 10 ? i - 8 : i < 22 ? (i - 10) % 4 : i - 22;
+            if constexpr (st == 0) mv[un] = fl.mel[un] * kMelScale;
+            else if constexpr (st == 1) mv[un] = __builtin_amdgcn_fmed3f(mv[un], -kHalfMax, kHalfMax);
+            else if constexpr (st == 2) mh[un] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){mv[2 * un], mv[2 * un + 1]}, f16x2));
+            else if constexpr (st == 3) mr[un] = (float)__builtin_bit_cast(f16x2, mh[un >> 1])[un & 1];
+            else if constexpr (st == 4) mr[un] = mv[un] - mr[un];
+            else if constexpr (st == 5) mr[un] = mr[un] * kLoScale;
+            else ml[un] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){mr[2 * un], mr[2 * un + 1]}, f16x2));
+        };
+        constexpr int NM = FIRST ? 24 : 0;
+        // how many of the NX x-part MFMAs go where: beside the r path; behind the r (.) h store while it lands (before barrier
+        // 1); into the LDS round trip behind barrier 1; beside the candidate path; behind the h store (before barrier 2); and
+        // (the tail) into the round trip behind barrier 2 at the top of the next frame
+        constexpr int XR = NX * 20 / 72, XW1 = NX * 6 / 72, XB1 = NX * 8 / 72, XC = NX * 26 / 72, XW2 = NX * 6 / 72,
+                      XB2 = NX - XR - XW1 - XB1 - XC - XW2;
+
+        // prologue: frame 0's x-part up to its tail
+        {
+            constexpr auto P0 = std::integral_constant<int, 0>{};
+            xbegin(P0, 0);
+            run<NX - XB2, 0>([&](auto i_) { X(P0, i_); });
         }
+#ifdef KWS_F16_TIMING
+        long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        long long tlast = __builtin_readcyclecounter();
+#endif
+        int slot1 = 1 % NS, slot2 = 2 % NS;      // xsb slots of frames t+1 and t+2
+
+        auto frame = [&](auto pc_, int t) {
+            constexpr int PC = decltype(pc_)::value, PN = PC ^ 1;
+            constexpr auto pc = std::integral_constant<int, PC>{};
+            constexpr auto pn = std::integral_constant<int, PN>{};
+            live = t < len_s ? 0xffffffffu : 0u;
+#ifdef KWS_F16_TIMING
+            tlast = __builtin_readcyclecounter();
+#endif
+            // ---- h(t-1) on its way; meanwhile the tail of this frame's own x-part ----
+            hread(hb, 0, 0);
+            hread(hb, 1, 1);
+            pin();
+            run<XB2, NX - XB2>([&](auto i_) { X(pc, i_); });
+            KWS_STAMP(0);
+            if constexpr (LAST) {
+                // the previous 16 frames' logits leave here, not at the end of frame t-1: between the x stream's tail and its next
+                // start the fewest registers are live, and the flush (softmax, decode rule, stores) needs ~60 of its own
+                if (t > 0 && (t & (kRingFrames - 1)) == 0) {
+                    lds_barrier();
+                    epilogue_flush(p.epi, epi, group, t - kRingFrames, kRingFrames, w, lane, false);
+                }
+            }
+            KWS_STAMP(9);
+            // the next frame's x-part starts beside the r path: its accumulators (bias), first input chunks and operand groups
+            // are requested now, a whole MFMA phase ahead
+            xbegin(pn, slot1);
+            pin();
+            // ---- recurrent part of r and u (48 MFMAs); FIRST: x(t+2) is prepared in their shadow ----
+            if constexpr (FIRST) {
+                zip<48, 0, NM, 0>([&](auto i_) { G(pc, i_); }, [&](auto i_) { Mq(i_); });
+                // every lane stores (the idle ones into a dump row behind the slots): a conditional store would let the compiler
+                // sink the whole stream into the branch, out of the MFMAs' shadow
+                *reinterpret_cast<uint2*>(xsb_dw + (xl_active ? slot2 * (KX * 2 * 64 * 4) + xs_lane : xs_dump)) = make_uint2(mh[0], mh[1]);
+                *reinterpret_cast<uint2*>(xsb_dw + (xl_active ? slot2 * (KX * 2 * 64 * 4) + 64 * 4 + xs_lane : xs_dump)) = make_uint2(ml[0], ml[1]);
+                fetch(fl, t + 3);
+                pin();
+            } else {
+                run<48, 0>([&](auto i_) { G(pc, i_); });
+            }
+            KWS_STAMP(1);
+            // ---- r, r (.) h, its split -> LDS; woven in: the head of the next frame's x-part ----
+            zip<NR, 0, XR, 0>([&](auto i_) { R(pc, i_); }, [&](auto i_) { X(pn, i_); });
+            KWS_STAMP(2);
+            rhb[(w * 2 + 0) * 64 + lane] = (u32x4){phi[0], phi[1], phi[2], phi[3]};
+            rhb[(w * 2 + 1) * 64 + lane] = (u32x4){plo[0], plo[1], plo[2], plo[3]};
+            pin();
+            run<XW1, XR>([&](auto i_) { X(pn, i_); });       // while the store lands
+            lds_barrier();            // #1: r (.) h visible; hb fully consumed; the slot of x(t) fully consumed
+            pin();
+            KWS_STAMP(3);
+            hread(rhb, 0, 0);
+            hread(rhb, 1, 1);
+            if constexpr (!FIRST) {
+                // x(t+2) -> the slot this frame's x-part has just released; request x(t+3)
+                commit(fl, slot2);
+                fetch(fl, t + 3);
+            }
+            pin();
+            run<XB1, XR + XW1>([&](auto i_) { X(pn, i_); });
+            KWS_STAMP(4);
+            // ---- candidate (24 MFMAs) with the u sigmoid in its shadow ----
+            zip<24, 0, NU, 0>([&](auto i_) { Cm(pc, i_); }, [&](auto i_) { U(pc, i_); });
+            KWS_STAMP(5);
+            // ---- tanh, state update, split -> LDS, seam / projection; woven in: more of the next frame's x-part ----
+            f16x8 wfc[2];
+            if constexpr (LAST) {
+                wfc[0] = as_f16x8(wfc_src[lane]);
+                wfc[1] = as_f16x8(wfc_src[64 + lane]);
+                pin();
+            }
+            zip<NC, 0, XC, XR + XW1 + XB1>([&](auto i_) { Cc(pc, i_); }, [&](auto i_) { X(pn, i_); });
+            KWS_STAMP(6);
+            u32x4 hhi = (u32x4){phi[0], phi[1], phi[2], phi[3]}, hlo = (u32x4){plo[0], plo[1], plo[2], plo[3]};
+            hb[(w * 2 + 0) * 64 + lane] = hhi;
+            hb[(w * 2 + 1) * 64 + lane] = hlo;
+            pin();
+            // the layer's OUTPUT row is zero past seq_len (dynamic_rnn), its state is copied through
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hhi[e] &= live; hlo[e] &= live; }
+            }
+            if constexpr (!LAST) {
+                u32x4* dst = seam_out + (size_t)t * (4 * 2 * 64);
+                dst[lane] = hhi;
+                dst[64 + lane] = hlo;
+            }
+            if constexpr (LAST) {
+                // dense: this wave's 32 units are exactly k-chunk w of Wfc^T
+                f32x4 fm = w == 0 ? bl[(3 * H) / 4 + g] : splat4(0.f), fl2 = splat4(0.f);
+                fm = mfma_f16(wfc[0], as_f16x8(hhi), fm);
+                fl2 = mfma_f16(wfc[1], as_f16x8(hhi), fl2);
+                fl2 = mfma_f16(wfc[0], as_f16x8(hlo), fl2);
+                pin();
+                run<XW2, XR + XW1 + XB1 + XC>([&](auto i_) { X(pn, i_); });     // while the h store lands and the projection drains
+                const f32x4 accf = combine(fm, fl2);
+                if (g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
+            } else {
+                run<XW2, XR + XW1 + XB1 + XC>([&](auto i_) { X(pn, i_); });
+            }
+            slot1 = slot2;
+            slot2 = slot2 + 1 == NS ? 0 : slot2 + 1;
+            pin();
+            KWS_STAMP(7);
+            lds_barrier();            // #2: h(t), x(t+2), the partial logits visible
+            pin();
+            KWS_STAMP(8);
+            if constexpr (LAST) {
+                if (w == (t & 3)) epilogue_fold(epi, t, lane);
+                if (t == T - 1) {          // the call's last block (a full one included: there is no next frame to flush it in)
+                    const int t0 = t & ~(kRingFrames - 1);
+                    lds_barrier();
+                    epilogue_flush(p.epi, epi, group, t0, t - t0 + 1, w, lane, true);
+                }
+            }
+            KWS_STAMP(9);
+        };
+        for (int t = 0; t < T; t += 2) {
+            frame(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < T) frame(std::integral_constant<int, 1>{}, t + 1);
+        }
+#ifdef KWS_F16_TIMING
+        if (g_timing && lane == 0 && group < 4)
+            for (int i = 0; i < 16; ++i) g_timing[((FIRST ? 0 : 16) + group * 4 + w) * 16 + i] = tsum[i];
+#endif
         if (bvalid) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -407,12 +611,12 @@ gru_layer_f16x3(const GruF16Params p) {
 
 bool gru_f16x3_supported(int hidden, int n_mel) { return hidden == 128 && n_mel % 4 == 0 && n_mel >= 4 && n_mel <= 64; }
 
-template <int KX, bool FIRST, bool LAST>
-static hipError_t launch_f16x3(const GruF16Params& p, hipStream_t st) {
+template <int KX, bool FIRST, bool LAST, bool MASKED>
+static hipError_t launch_f16x3m(const GruF16Params& p, hipStream_t st) {
     const size_t lds = gru_f16x3_lds_bytes(KX, FIRST, LAST);
     static LdsGrant granted;
     {
-        const hipError_t e = grant_dynamic_lds(gru_layer_f16x3<KX, FIRST, LAST>, granted, lds);
+        const hipError_t e = grant_dynamic_lds(gru_layer_f16x3<KX, FIRST, LAST, MASKED>, granted, lds);
         if (e != hipSuccess) return e;
     }
     const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
@@ -426,8 +630,36 @@ static hipError_t launch_f16x3(const GruF16Params& p, hipStream_t st) {
             cu_cache[dev].store(cus, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((gru_layer_f16x3<KX, FIRST, LAST>), dim3(groups < cus ? groups : cus), dim3(256), lds, st, p);
+#ifdef KWS_F16_TIMING
+    static long long* tbuf = nullptr;
+    if (!tbuf) {
+        (void)hipMalloc(&tbuf, 32 * 16 * 8);
+        (void)hipMemset(tbuf, 0, 32 * 16 * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timing), &tbuf, sizeof(tbuf));
+    }
+#endif
+    hipLaunchKernelGGL((gru_layer_f16x3<KX, FIRST, LAST, MASKED>), dim3(groups < cus ? groups : cus), dim3(256), lds, st, p);
+#ifdef KWS_F16_TIMING
+    if (getenv("KWS_F16_TIMING")) {
+        (void)hipDeviceSynchronize();
+        long long h[32 * 16];
+        (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+        const int base = FIRST ? 0 : 16;
+        static const char* nm[16] = {"top+xtail", "G", "R|X", "wr+bar1", "rd+X", "Cm|U", "Cc|X", "tailwork", "bar2", "epilogue", "G0", "G1", "G2", "-", "-", "-"};
+        fprintf(stderr, "f16x3 %s T=%d cycles/frame (group 0, waves 0..3):", FIRST ? "first" : "upper", p.T);
+        for (int i = 0; i < 13; ++i)
+            fprintf(stderr, " %s=%lld/%lld/%lld/%lld", nm[i], h[(base + 0) * 16 + i] / p.T, h[(base + 1) * 16 + i] / p.T, h[(base + 2) * 16 + i] / p.T,
+                    h[(base + 3) * 16 + i] / p.T);
+        fprintf(stderr, "\n");
+    }
+#endif
     return hipGetLastError();
+}
+
+// the copy-through past seq_len costs 16 VALU instructions per frame: its own instantiation, used only when lengths are given
+template <int KX, bool FIRST, bool LAST>
+static hipError_t launch_f16x3(const GruF16Params& p, hipStream_t st) {
+    return p.seq_len ? launch_f16x3m<KX, FIRST, LAST, true>(p, st) : launch_f16x3m<KX, FIRST, LAST, false>(p, st);
 }
 
 hipError_t launch_gru_layer_f16x3(const GruF16Params& p, bool first, bool last, hipStream_t st) {

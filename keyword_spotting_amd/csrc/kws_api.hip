@@ -423,9 +423,10 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
         // (the kernel feeds mel * 2^-8: both exact) so that mel magnitudes far beyond fp16's 65504 stay representable.
         const float* q = static_cast<const float*>(weights_blob);
         for (size_t i = 0; i < weights_floats(cfg); ++i)
-            if (!(std::fabs(q[i]) < 128.0f)) {
+            if (!(std::fabs(q[i]) < 64.0f)) {
                 delete m;
-                return fail(KWS_ERR_UNSUPPORTED, "f16x3 path: weight %zu = %g is outside (-128, 128) (fp16 operands; x-part scaled by 256)", i, (double)q[i]);
+                return fail(KWS_ERR_UNSUPPORTED, "f16x3 path: weight %zu = %g is outside (-64, 64) (fp16 operands; x-part scaled by 256, "
+                            "candidate by 2 log2 e)", i, (double)q[i]);
             }
         int in_l = cfg->n_mel;
         m->f16_kx0 = (cfg->n_mel + 31) / 32;
@@ -450,7 +451,10 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
                                 } else {
                                     row = in_l + bf16_unit(c - kx, g, j);
                                 }
-                                const float v = ok ? scale * wq(Wg, Wc, H, gq, row, n * 16 + i) : 0.f;
+                                // the exponent scale of the gate's activation rides in the weights: sigmoid(a) = 1 / (1 + exp2(-a log2 e)),
+                                // tanh(a) = 1 - 2 / (1 + exp2(2 a log2 e)) -- the kernel applies exp2 to the pre-activation as it is
+                                const float act = gq == 2 ? 2.0f * 1.4426950408889634f : -1.4426950408889634f;
+                                const float v = ok ? scale * (act * wq(Wg, Wc, H, gq, row, n * 16 + i)) : 0.f;
                                 uint16_t hi, lo;
                                 f16_split(v, &hi, &lo);
                                 const size_t base = (((size_t)(n * 3 + gq) * kc + c) * 2) * 64;

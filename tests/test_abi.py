@@ -137,7 +137,8 @@ import sys
 sys.path.insert(0, %r)
 from keyword_spotting_amd import _lib, get_config, weights
 from keyword_spotting_amd.rnn_ctc import DeployModel
-for kw in (dict(), dict(precision="bf16"), dict(precision="int8"), dict(n_mel=60, hidden_size=256, num_layers=4), dict(n_mel=60, num_layers=1)):
+for kw in (dict(), dict(precision="bf16"), dict(precision="int8"), dict(n_mel=60, hidden_size=256, num_layers=4), dict(n_mel=60, num_layers=1),
+           dict(precision="f16x3"), dict(precision="f16x3", n_mel=32, num_layers=3)):
     cfg = get_config(**kw)
     try:
         m = DeployModel(cfg, weights.init_weights(cfg, seed=0))
@@ -162,10 +163,10 @@ def _run_selftest_process(env_extra):
 def test_selftest_passes_on_this_build_for_every_precision_and_kernel_family():
     """kws_selftest: TensorFlow's published GRUCell constants + a host fp64 loop, inside the library."""
     lines = _run_selftest_process({})
-    assert len(lines) == 5 and all(ln.startswith("PASS") for ln in lines), lines
+    assert len(lines) == 7 and all(ln.startswith("PASS") for ln in lines), lines
     # ... and as the create-time hook (KWS_SELFTEST=1 is read once per process, hence the subprocess)
     lines = _run_selftest_process({"KWS_SELFTEST": "1"})
-    assert len(lines) == 5 and all(ln.startswith("PASS") for ln in lines), lines
+    assert len(lines) == 7 and all(ln.startswith("PASS") for ln in lines), lines
 
 
 @pytest.mark.gpu
