@@ -180,14 +180,18 @@ def test_selftest_catches_a_miscompiled_build():
     correct results and pass every GPU test, so they cannot serve as one; tools/exp_selftest_variants.py.)"""
     import shutil
     import subprocess
+    import glob
     so = os.path.join(ROOT, "variants", "libkws_vgprform.so")
-    if not os.path.exists(so):
+    newest = max(os.path.getmtime(f) for f in glob.glob(os.path.join(ROOT, "keyword_spotting_amd", "csrc", "*.h*")) +
+                 [os.path.join(ROOT, "include", "kws_amd.h")])
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
         if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
             pytest.skip("no hipcc to build the variant")
         subprocess.check_call([os.path.join(ROOT, "tools", "build_variant.sh"), "vgprform", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
     lines = _run_selftest_process({"KWS_AMD_LIB": so})
     bad = [ln for ln in lines if ln.startswith("FAIL")]
-    assert bad and all("kws_selftest" in ln and "gru_layer_resident" in ln and "lang" in ln for ln in bad), lines
+    assert bad and all("kws_selftest" in ln and "lang" in ln for ln in bad), lines
+    assert any("gru_layer_resident" in ln for ln in bad), lines
     assert any("'num_layers': 1" in ln for ln in bad), lines
     lines = _run_selftest_process({"KWS_AMD_LIB": so, "KWS_SELFTEST": "1"})             # refused at kws_create
     assert any(ln.startswith("FAIL") and "kws_selftest" in ln for ln in lines), lines
