@@ -199,7 +199,7 @@ def secondary_lines(device):
     mgr.close()
     m.close()
     del pcm_big
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "f16x3", "bf16"):
         cfg = get_config(precision=prec)
         m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
         fe, mgr = MelFrontend(cfg), StreamManager(m, B)
@@ -240,6 +240,12 @@ def secondary_lines(device):
                                               "frac": alg / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg,
                                               "traffic": traffic, "traffic_source": src,
                                               "kernel_ms_rocprof": rp_ms, "rocprof_source": rp_src}}
+        elif prec == "f16x3":
+            per = [k_[0] / max(k_[1], 1) for k_ in kt]
+            entry["gru_kernels"] = [{"kernel": m.kernel_names()[l], "kernel_ms": per[l],
+                                     "tflops_issued": 3 * FLOP_PER_FRAME["layer"][l] * frames / (per[l] * 1e-3) / 1e12,
+                                     "frac": 3 * FLOP_PER_FRAME["layer"][l] * frames / (per[l] * 1e-3) / 1e12 / 2500.0}
+                                    for l in range(len(per))]
         else:
             ms = kt[0][0] / max(kt[0][1], 1)
             entry["gru_kernels"] = [{"kernel": m.kernel_names()[0], "kernel_ms": ms,

@@ -123,6 +123,7 @@ constexpr int lds_groups() {
 }
 
 #ifdef KWS_F16_TIMING       // tools/build_variant.sh timing -DKWS_F16_TIMING; tools/exp_f16_timing.py: cycles per phase of the frame loop
+                            // (every stamp is an s_memtime + s_waitcnt: ~100 cycles that land in the NEXT interval)
 __device__ long long* g_timing = nullptr;
 #define KWS_STAMP(i) do { const long long now_ = __builtin_readcyclecounter(); tsum[i] += now_ - tlast; tlast = now_; } while (0)
 #else
@@ -485,11 +486,24 @@ gru_layer_f16x3(const GruF16Params p) {
 #ifdef KWS_F16_TIMING
             tlast = __builtin_readcyclecounter();
 #endif
+            // ---- LAST: the previous frame's four partial logit vectors -> one row of the 16-frame ring.  Every wave folds its own
+            // four streams (lane & 7 = (stream, half); the other lanes repeat the same reads and the same store), reads first,
+            // sum behind the x tail: nobody falls a whole LDS round trip behind the others, as a single folding wave would
+            f32x4 fr[4];
+            const int fold_s = 4 * w + ((lane & 7) >> 1), fold_h = lane & 1;
+            if constexpr (LAST) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fr[k] = *reinterpret_cast<const f32x4*>(epi.pstage + (k * 16 + fold_s) * 8 + 4 * fold_h);
+            }
             // ---- h(t-1) on its way; meanwhile the tail of this frame's own x-part ----
             hread(hb, 0, 0);
             hread(hb, 1, 1);
             pin();
             run<XB2, NX - XB2>([&](auto i_) { X(pc, i_); });
+            if constexpr (LAST) {
+                if (t > 0) *reinterpret_cast<f32x4*>(epi.lring + ((((t - 1) & (kRingFrames - 1)) * 16 + fold_s) * 8 + 4 * fold_h)) = ((fr[0] + fr[1]) + fr[2]) + fr[3];
+                pin();
+            }
             KWS_STAMP(0);
             if constexpr (LAST) {
                 // the previous 16 frames' logits leave here, not at the end of frame t-1: between the x stream's tail and its next
@@ -584,9 +598,13 @@ gru_layer_f16x3(const GruF16Params p) {
             pin();
             KWS_STAMP(8);
             if constexpr (LAST) {
-                if (w == (t & 3)) epilogue_fold(epi, t, lane);
-                if (t == T - 1) {          // the call's last block (a full one included: there is no next frame to flush it in)
+                if (t == T - 1) {          // the call's last frame and block (a full one included): no next frame to do it in
                     const int t0 = t & ~(kRingFrames - 1);
+                    const int fs = 4 * w + ((lane & 7) >> 1), fh = lane & 1;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(epi.pstage + (0 * 16 + fs) * 8 + 4 * fh);
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) v += *reinterpret_cast<const f32x4*>(epi.pstage + (k * 16 + fs) * 8 + 4 * fh);
+                    *reinterpret_cast<f32x4*>(epi.lring + (((t & (kRingFrames - 1)) * 16 + fs) * 8 + 4 * fh)) = v;
                     lds_barrier();
                     epilogue_flush(p.epi, epi, group, t0, t - t0 + 1, w, lane, true);
                 }
@@ -645,9 +663,9 @@ static hipError_t launch_f16x3m(const GruF16Params& p, hipStream_t st) {
         long long h[32 * 16];
         (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
         const int base = FIRST ? 0 : 16;
-        static const char* nm[16] = {"top+xtail", "G", "R|X", "wr+bar1", "rd+X", "Cm|U", "Cc|X", "tailwork", "bar2", "epilogue", "G0", "G1", "G2", "-", "-", "-"};
+        static const char* nm[16] = {"top+xtail", "G", "R|X", "wr+bar1", "rd+X", "Cm|U", "Cc|X", "tailwork", "bar2", "epilogue", "-", "-", "-", "-", "-", "-"};
         fprintf(stderr, "f16x3 %s T=%d cycles/frame (group 0, waves 0..3):", FIRST ? "first" : "upper", p.T);
-        for (int i = 0; i < 13; ++i)
+        for (int i = 0; i < 10; ++i)
             fprintf(stderr, " %s=%lld/%lld/%lld/%lld", nm[i], h[(base + 0) * 16 + i] / p.T, h[(base + 1) * 16 + i] / p.T, h[(base + 2) * 16 + i] / p.T,
                     h[(base + 3) * 16 + i] / p.T);
         fprintf(stderr, "\n");

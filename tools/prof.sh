@@ -28,6 +28,8 @@ python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 mkdir -p $OUT/commit
 cp $OUT/summary.txt $OUT/commit/${TAG}_rocprofv3_summary.txt
+# the kernel sources this set was taken from: bench.py quotes a committed profile only while this still matches the build
+python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import bench; print(bench.csrc_hash())" > $OUT/commit/${TAG}_source_hash.txt
 cp $OUT/pmc.json $OUT/commit/${TAG}_pmc.json
 cp $OUT/trace/*kernel_stats.csv $OUT/commit/${TAG}_kernel_stats.csv 2>/dev/null
 # the bench line of the traced run: JSON for bench.py, the last text lines for the other drivers
