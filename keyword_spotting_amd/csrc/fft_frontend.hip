@@ -17,6 +17,8 @@
 // frames).  In stage 2 lane = (g, frame f of 16) takes k1 = 4q + g in pass q (= wave q); the magnitudes return to LDS in BIN
 // order, where the mel projection (v_mfma_f32_16x16x4_f32 over 4-bin groups) only touches the blocks of the basis that are
 // not all zero.  ~9 kflop per frame on the VALU instead of the 100 kflop of the dense contraction.
+#include <cstdlib>
+
 #include "gru_device.h"
 #include "vad_device.h"
 
@@ -92,10 +94,10 @@ constexpr int kSpecRows = 208;                 // spectrum rows (bins 0..200 + z
 // 52 MFMAs per 16 frames for 40 filters where the dense product takes 156.  Wave m = tile m.
 // 26 KiB of LDS per workgroup (the spectrum reuses the transpose planes): six workgroups = 24 waves per CU.
 // SampleT: float samples, or int16 PCM as the sound card delivers it (detector.py:40-43,74-79: scaled by 2^-15 on load --
-// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along -- one wave of the
-// workgroup in which a stream's first frame lies takes the vad sum of that stream's new samples (the masks silent / reset)
-// and writes its next sample carry: the same rows this workgroup and its XCD neighbours transform, so the PCM is fetched
-// from HBM once (r3: the gate of stream k sat in workgroup k, on another XCD -- 1.7x the algorithmic read traffic).
+// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along in the same launch as
+// extra "gate" workgroups in front of the transform blocks: vad sum of a stream's new samples (the masks silent / reset) and
+// its next sample carry, taken on the XCD that transforms that stream, so the PCM is fetched from HBM once (r3: the gate of
+// stream k sat in transform workgroup k, on another XCD -- 1.7x the algorithmic read traffic and +9 us per launch).
 #ifndef KWS_FE_OCC
 #define KWS_FE_OCC 6          // workgroups per CU the register allocation aims at (tools/build_variant.sh -DKWS_FE_OCC=n for A/B)
 #endif
@@ -109,14 +111,54 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
     const unsigned total = (unsigned)p.B * (unsigned)p.T;
     // XCD-aware block -> frame-block map.  Workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2;
     // a stream's frames span two or three 16-frame blocks, every frame re-reads 240 samples of its predecessor, and the
-    // gate below reads the whole row of a stream that starts in this block.  Giving XCD x the CONTIGUOUS run of blocks
+    // gate blocks read the whole rows of the same streams.  Giving XCD x the CONTIGUOUS run of blocks
     // [x G/8, (x+1) G/8) keeps all readers of a row behind one L2, so the PCM leaves HBM once (the grid is a multiple of 8).
-    const unsigned blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const unsigned f0 = blk * 16u;
-    if (f0 >= total) return;                            // padding block of the rounded-up grid (uniform: before any barrier)
+    // GATE: the first p.gate_blocks workgroups (a multiple of 8, so the XCD of every later block is unchanged) do not transform:
+    // they are the head of the stream-manager iteration, see the end of this function.
+    const unsigned gate_blocks = GATE ? (unsigned)p.gate_blocks : 0u;
+    const unsigned fft_grid = gridDim.x - gate_blocks;
     constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
     const SampleT* chunk_all = sizeof(SampleT) == 2 ? reinterpret_cast<const SampleT*>(p.pcm_i16) : reinterpret_cast<const SampleT*>(p.pcm);
     const int n_chunk = p.n_samples - p.n_carry;
+    if constexpr (GATE) {
+        if (blockIdx.x < gate_blocks) {
+            // vad over the new samples -> silent / reset masks, and the next sample carry (detector.py:168-183), for the streams
+            // whose frames THIS XCD's transform blocks read: XCD x transforms frame blocks [x G/8, (x+1) G/8), i.e. the streams
+            // whose first frame lies in there, and its gate blocks take those streams, kGateStreams each.  They are dispatched
+            // first, run beside the transform blocks instead of in front of or behind them (round 3 / early round 4: +9 us per
+            // launch), and whoever touches a PCM row first brings it into the L2 the other one reads it from.
+            // block_abs_sum IS kws_vad's summation (same association, same bits): all VAD sites decide identically.
+            const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3, T = (unsigned)p.T;
+            const unsigned f_lo = 16u * x * (fft_grid >> 3), f_hi = 16u * (x + 1) * (fft_grid >> 3);
+            unsigned s_lo = (f_lo + T - 1) / T, s_hi = (f_hi + T - 1) / T;
+            s_lo = s_lo < (unsigned)p.B ? s_lo : (unsigned)p.B;
+            s_hi = s_hi < (unsigned)p.B ? s_hi : (unsigned)p.B;
+            const unsigned per = (gate_blocks >> 3);                              // gate blocks per XCD
+            const unsigned each = (s_hi - s_lo + per - 1) / (per ? per : 1);      // streams per gate block of this XCD
+            const unsigned b_end = s_lo + (j + 1) * each < s_hi ? s_lo + (j + 1) * each : s_hi;
+            for (unsigned b0 = s_lo + j * each; b0 < b_end; b0 += 4) {            // four streams per pass, workgroup-uniform
+                const SampleT* rows[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rows[r] = chunk_all + (size_t)(b0 + r < b_end ? b0 + r : b_end - 1) * n_chunk;
+                float sums[4];
+                block_abs_sum_rows<SampleT, 4>(rows, n_chunk, sums);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned bs = b0 + r;
+                    if (bs < b_end) {
+                        if (tid == 0) vad_masks(sums[r], p.vad_thres, bs, p.restart, p.silent, p.reset);
+                        carry_tail<SampleT>(p.carry + (size_t)bs * p.n_carry, p.n_carry, rows[r], n_chunk, p.next + (size_t)bs * p.n_next, p.n_next, tid, 256);
+                    }
+                }
+                __syncthreads();         // the partial sums in LDS are reused by the next pass
+            }
+            return;
+        }
+    }
+    const unsigned bid = blockIdx.x - gate_blocks;
+    const unsigned blk = (bid & 7u) * (fft_grid >> 3) + (bid >> 3);
+    const unsigned f0 = blk * 16u;
+    if (f0 >= total) return;                            // padding block of the rounded-up grid (uniform: before any barrier)
 #ifdef KWS_FE_TIMING       // tools/ubench/fe_phases.hip: s_memtime at the phase boundaries of every wave
 #define KWS_FE_STAMP(i) do { if (lane == 0) p.timing[((size_t)blk * 4 + w) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -324,22 +366,6 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
             }
         }
     }
-    if constexpr (GATE) {
-        // The head of the stream-manager iteration, by the wave with the least to do after the last barrier (no mel tile
-        // for 40 filters): workgroup k takes stream k's vad sum -- wave_abs_sum: the bits of kws_vad's block sum -- the
-        // masks and the next carry while the other waves finish the projection.  No workgroup barrier: wave-private.
-        // The stream(s) whose FIRST frame lies in this block: their rows are what this workgroup (and its neighbours on the
-        // same XCD) transform, so the sum's reads are L2 hits or bring the row in for them.
-        if (w == 3) {
-            const unsigned T = (unsigned)p.T;
-            for (unsigned bs = (f0 + T - 1) / T; bs < (unsigned)p.B && bs * T < f0 + 16u; ++bs) {
-                const SampleT* row = chunk_all + (size_t)bs * n_chunk;
-                const float sum = wave_abs_sum<SampleT>(row, n_chunk, lane);
-                if (lane == 0) vad_masks(sum, p.vad_thres, bs, p.restart, p.silent, p.reset);
-                carry_tail<SampleT>(p.carry + (size_t)bs * p.n_carry, p.n_carry, row, n_chunk, p.next + (size_t)bs * p.n_next, p.n_next, lane, 64);
-            }
-        }
-    }
     KWS_FE_STAMP(7);
 }
 
@@ -358,8 +384,14 @@ static hipError_t launch_fft400_tiles(const FrontendParams& p, unsigned grid, hi
 hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st) {
     const long long total = (long long)B * p.T;        // < 2^31 (checked by the caller)
     const unsigned grid = (unsigned)(((total + 15) / 16 + 7) / 8 * 8);     // multiple of 8: the kernel's XCD-aware block map
-    if (p.pcm_i16) return p.gate ? launch_fft400_tiles<int16_t, true>(p, grid, st) : launch_fft400_tiles<int16_t, false>(p, grid, st);
-    return p.gate ? launch_fft400_tiles<float, true>(p, grid, st) : launch_fft400_tiles<float, false>(p, grid, st);
+    if (!p.gate) return p.pcm_i16 ? launch_fft400_tiles<int16_t, false>(p, grid, st) : launch_fft400_tiles<float, false>(p, grid, st);
+    // gate blocks: kGateStreams streams each (four rows per pass), the same number on every XCD.  16 measured best at 4096 x 3600
+    // samples (tools/exp_gate_ab.sh: 1/2/4/8/16/24/32 -> 44.4/43.2/40.7/38.2/36.5/41.7/48.9 us per fused launch; 32.3 without the gate)
+    static const unsigned kGateStreams = [] { const char* e = getenv("KWS_FE_GATE_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 16u; }();
+    FrontendParams q = p;
+    q.gate_blocks = (int)(8u * (((unsigned)B + 8u * kGateStreams - 1) / (8u * kGateStreams) + 1u));
+    return p.pcm_i16 ? launch_fft400_tiles<int16_t, true>(q, grid + (unsigned)q.gate_blocks, st)
+                     : launch_fft400_tiles<float, true>(q, grid + (unsigned)q.gate_blocks, st);
 }
 
 }  // namespace kws

@@ -174,6 +174,7 @@ struct FrontendParams {
     // fft_frontend.hip only, the head of a stream-manager iteration fused into the same launch (gate != 0): vad over the new
     // samples -> silent / reset masks, and the next sample carry (the last n_next samples of [carry | chunk])
     int gate;
+    int gate_blocks;         // set by launch_mel_fft400: leading workgroups that take the gate instead of transforming (multiple of 8)
     float vad_thres;
     const uint8_t* restart;
     uint8_t* silent;
