@@ -131,7 +131,8 @@ def test_test2_chunked_replay():
             np.testing.assert_array_equal(words[s, :counts[s]].cpu().numpy(), D.ctc_decode(sm[s])[1::2])
 
 
-def test_stream_manager_equals_host_detector():
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_stream_manager_equals_host_detector(precision):
     """Device-side window (kws_window_step) == the SimpleQueue/ctc_decode2/ctc_predict loop, stream by stream,
     including eviction past 15 chunks, silence clears and trigger restarts."""
     from keyword_spotting_amd import get_config
@@ -143,7 +144,7 @@ def test_stream_manager_equals_host_detector():
     mel = torch.from_numpy(G.synthetic_mel(b, sum(chunks), 40, seed=95)).cuda()
     rng = np.random.default_rng(96)
     speech = rng.random((len(chunks), b)) > 0.05
-    cfg = get_config()
+    cfg = get_config(precision=precision)
     for label in ("12", "1233", "3"):
         det = HotwordDetector(DeployModel(cfg, w), batch=b, label=label)
         mgr = StreamManager(DeployModel(cfg, w), batch=b, label=label)

@@ -149,7 +149,7 @@ def test_reserved_scratch_is_never_regrown_and_layouts_can_alternate():
     assert torch.equal(r["logits"], one["logits"])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x3"])
 def test_more_stream_groups_than_cus_persistent_workgroups(precision):
     """B = 8200 streams = 513 groups of 16 (the last one ragged) on 256 CUs: the resident / bf16 kernels stage their weights once
     per workgroup and walk groups blockIdx, blockIdx + 256, ...  A stream's result must not depend on which workgroup, in

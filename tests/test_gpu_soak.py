@@ -16,7 +16,7 @@ def _model(w, n_mel=40, layers=2, kernel="auto", precision="fp32"):
     return DeployModel(get_config(n_mel=n_mel, num_layers=layers, precision=precision), w, kernel=kernel)
 
 
-@pytest.mark.parametrize("precision,layers", [("fp32", 2), ("fp32", 1), ("bf16", 2), ("bf16", 1)])
+@pytest.mark.parametrize("precision,layers", [("fp32", 2), ("fp32", 1), ("bf16", 2), ("bf16", 1), ("f16x3", 2), ("f16x3", 1), ("f16x3", 3)])
 def test_fresh_handles_and_repeats_are_bit_identical(precision, layers):
     w = G.random_weights(40, 128, layers, 6, seed=301)
     rng = np.random.default_rng(302)
@@ -146,6 +146,8 @@ def test_no_stale_data_leaks_between_calls():
              ("pipelined 4x256", get_config(n_mel=60, hidden_size=256, num_layers=4), 1024, 24, "auto"),
              ("pipelined 8x64", get_config(hidden_size=64, num_layers=8), 512, 24, "auto"),
              ("bf16", get_config(precision="bf16"), 4096, 24, "auto"),
+             ("f16x3", get_config(precision="f16x3"), 4096, 24, "auto"),
+             ("f16x3, three layers, odd frame count", get_config(precision="f16x3", num_layers=3), 1000, 23, "auto"),
              ("fp32 resident", get_config(), 4096, 24, "auto"),
              ("fp32 resident, layers overlapped on streams", get_config(), 1024, 96, "auto")]
     g = torch.Generator(device="cuda").manual_seed(77)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the native loop (kws_stream_feed) against the HotwordDetector mirror of detector.py:158-209: random
 chunk lengths (empty, sub-frame, odd, long), int16 / float PCM, silent stretches, several window sizes and batch sizes,
-fp32 and bf16 stacks.  Every chunk: identical hits and bit-identical recurrent state.  usage: fuzz_stream.py [seeds]"""
+fp32, f16x3 and bf16 stacks.  Every chunk: identical hits and bit-identical recurrent state.  usage: fuzz_stream.py [seeds]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,7 +15,7 @@ seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 bad = 0
 for seed in range(seeds):
     rng = np.random.default_rng(1000 + seed)
-    prec = "bf16" if seed % 3 == 2 else "fp32"
+    prec = ("fp32", "f16x3", "bf16", "fp32", "f16x3")[seed % 5]
     n_mel = 60 if seed % 4 == 1 else 40
     cfg = get_config(precision=prec, n_mel=n_mel)
     w = weights.init_weights(cfg, seed=seed)

@@ -64,6 +64,8 @@ tot += repeat("pipelined 8xGRU h=64", get_config(hidden_size=64, num_layers=8), 
 tot += repeat("int8 graph", get_config(precision="int8"), 4096, 40, n)
 tot += repeat("int8 graph, ragged batch", get_config(precision="int8"), 1000, 23, n)
 tot += repeat("bf16 stack", get_config(precision="bf16"), 4096, 100, n)
+tot += repeat("f16x3 stack", get_config(precision="f16x3"), 4096, 100, n)
+tot += repeat("f16x3 stack, persistent over 513 groups, ragged", get_config(precision="f16x3"), 8200, 23, n)
 tot += repeat("fp32 resident", get_config(), 4096, 100, n)
 tot += repeat("fp32 resident, layers overlapped on streams", get_config(), 1024, 200, n)
 tot += repeat("fp32 resident 4 layers, overlapped", get_config(num_layers=4), 1024, 130, n)
