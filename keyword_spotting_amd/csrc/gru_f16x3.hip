@@ -310,26 +310,28 @@ gru_layer_f16x3(const GruF16Params p) {
         // ~12..18 further on need.
         f16x8 xb[2][2], wtmp[2][2][2];
         int xs_off[2] = {lane, lane};            // element offset of the slot the x stream of each parity reads, + lane
-        auto xbegin = [&](auto pn_, int slot) {   // accumulators from the bias, first two chunks and operand groups on their way
+        // E: what the x stream of parity PN needs before its first MFMA, one LDS read per element -- the accumulators' start values
+        // (the biases; the lo accumulators start from the MFMA's inline 0), the first two input chunks, the first two streamed
+        // operand groups.  These ride under the G MFMAs of the frame before, a whole phase ahead of their first use.
+        constexpr int NE0 = 6, NE1 = 2 * (KX < 2 ? KX : 2), NE2 = 4 * (NG < 2 ? NG : 2), NE = NE0 + NE1 + NE2;
+        auto E = [&](auto pn_, auto i_) {
+            constexpr int PN = decltype(pn_)::value, i = decltype(i_)::value;
+            if constexpr (i < NE0) {
+                constexpr int q = i / 2, j = i % 2;
+                am[PN][j][q] = bl[(q * H + (2 * w + j) * 16) / 4 + g];
+                al[PN][j][q] = splat4(0.f);
+            } else if constexpr (i < NE0 + NE1) {
+                constexpr int c = (i - NE0) / 2, hl = (i - NE0) % 2;
+                xb[c][hl] = as_f16x8(xsb[xs_off[PN] + (c * 2 + hl) * 64]);
+            } else {
+                constexpr int k = (i - NE0 - NE1) / 4, jh = (i - NE0 - NE1) % 4;
+                wtmp[k][jh >> 1][jh & 1] = as_f16x8(wul_w[(k * 4 + jh) * 64]);
+            }
+        };
+        auto xbegin = [&](auto pn_, int slot) {   // un-woven form (prologue)
             constexpr int PN = decltype(pn_)::value;
             xs_off[PN] = slot * (KX * 2 * 64) + lane;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    am[PN][j][q] = bl[(q * H + (2 * w + j) * 16) / 4 + g];
-                    al[PN][j][q] = splat4(0.f);
-                }
-            static_for<0, (KX < 2 ? KX : 2)>([&](auto c_) {
-                constexpr int c = decltype(c_)::value;
-                xb[c][0] = as_f16x8(xsb[xs_off[PN] + (c * 2 + 0) * 64]);
-                xb[c][1] = as_f16x8(xsb[xs_off[PN] + (c * 2 + 1) * 64]);
-            });
-            static_for<0, (NG < 2 ? NG : 2)>([&](auto k_) {
-                constexpr int k = decltype(k_)::value;
-#pragma unroll
-                for (int jh = 0; jh < 4; ++jh) wtmp[k][jh >> 1][jh & 1] = as_f16x8(wul_w[(k * 4 + jh) * 64]);
-            });
+            static_for<0, NE>([&](auto i_) { E(pn_, i_); });
         };
         auto X = [&](auto pn_, auto i_) {
             constexpr int PN = decltype(pn_)::value, i = decltype(i_)::value;
@@ -516,11 +518,15 @@ gru_layer_f16x3(const GruF16Params p) {
             KWS_STAMP(9);
             // the next frame's x-part starts beside the r path: its accumulators (bias), first input chunks and operand groups
             // are requested now, a whole MFMA phase ahead
-            xbegin(pn, slot1);
+            xs_off[PN] = slot1 * (KX * 2 * 64) + lane;
             pin();
-            // ---- recurrent part of r and u (48 MFMAs); FIRST: x(t+2) is prepared in their shadow ----
+            // ---- recurrent part of r and u (48 MFMAs); in their shadow: the E reads, FIRST: x(t+2) is prepared ----
             if constexpr (FIRST) {
-                zip<48, 0, NM, 0>([&](auto i_) { G(pc, i_); }, [&](auto i_) { Mq(i_); });
+                zip<48, 0, NE + NM, 0>([&](auto i_) { G(pc, i_); }, [&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i < NE) E(pn, i_);
+                    else Mq(std::integral_constant<int, i - NE>{});
+                });
                 // every lane stores (the idle ones into a dump row behind the slots): a conditional store would let the compiler
                 // sink the whole stream into the branch, out of the MFMAs' shadow
                 *reinterpret_cast<uint2*>(xsb_dw + (xl_active ? slot2 * (KX * 2 * 64 * 4) + xs_lane : xs_dump)) = make_uint2(mh[0], mh[1]);
@@ -528,7 +534,7 @@ gru_layer_f16x3(const GruF16Params p) {
                 fetch(fl, t + 3);
                 pin();
             } else {
-                run<48, 0>([&](auto i_) { G(pc, i_); });
+                zip<48, 0, NE, 0>([&](auto i_) { G(pc, i_); }, [&](auto i_) { E(pn, i_); });
             }
             KWS_STAMP(1);
             // ---- r, r (.) h, its split -> LDS; woven in: the head of the next frame's x-part ----
