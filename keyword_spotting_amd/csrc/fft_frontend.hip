@@ -113,39 +113,42 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
     // a stream's frames span two or three 16-frame blocks, every frame re-reads 240 samples of its predecessor, and the
     // gate blocks read the whole rows of the same streams.  Giving XCD x the CONTIGUOUS run of blocks
     // [x G/8, (x+1) G/8) keeps all readers of a row behind one L2, so the PCM leaves HBM once (the grid is a multiple of 8).
-    // GATE: the first p.gate_blocks workgroups (a multiple of 8, so the XCD of every later block is unchanged) do not transform:
-    // they are the head of the stream-manager iteration, see the end of this function.
-    const unsigned gate_blocks = GATE ? (unsigned)p.gate_blocks : 0u;
-    const unsigned fft_grid = gridDim.x - gate_blocks;
+    // GATE: besides the transform blocks the grid holds "gate" blocks -- the head of the stream-manager iteration: vad over the new
+    // samples -> silent / reset masks, and the next sample carry (detector.py:168-183).  Workgroups go round-robin over the 8 XCDs
+    // (blockIdx % 8), each with its own L2, and are dispatched in index order.  XCD x transforms the CONTIGUOUS run of frame
+    // blocks [x F, (x+1) F), F = fft_blocks / 8 (a stream's frames span two or three blocks and re-read 240 samples each: one L2
+    // serves them all), and in its sequence every gate block sits IN FRONT OF the p.gate_run transform blocks whose streams
+    // (first frame inside that run) it handles: the gate brings a PCM row into the L2 the transforms then read it from, or
+    // the other way round -- the PCM leaves HBM once (round 3: 1.72x), and the gate runs beside the transforms, not behind
+    // them (round 3: +9 us per launch).  block_abs_sum IS kws_vad's summation (same association, same bits).
     constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
     const SampleT* chunk_all = sizeof(SampleT) == 2 ? reinterpret_cast<const SampleT*>(p.pcm_i16) : reinterpret_cast<const SampleT*>(p.pcm);
     const int n_chunk = p.n_samples - p.n_carry;
+    const unsigned xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;       // XCD, position in that XCD's sequence
+    const unsigned F = (unsigned)p.fft_blocks >> 3;                   // transform blocks per XCD
+    unsigned local = seq;                                               // this XCD's transform block index
     if constexpr (GATE) {
-        if (blockIdx.x < gate_blocks) {
-            // vad over the new samples -> silent / reset masks, and the next sample carry (detector.py:168-183), for the streams
-            // whose frames THIS XCD's transform blocks read: XCD x transforms frame blocks [x G/8, (x+1) G/8), i.e. the streams
-            // whose first frame lies in there, and its gate blocks take those streams, kGateStreams each.  They are dispatched
-            // first, run beside the transform blocks instead of in front of or behind them (round 3 / early round 4: +9 us per
-            // launch), and whoever touches a PCM row first brings it into the L2 the other one reads it from.
-            // block_abs_sum IS kws_vad's summation (same association, same bits): all VAD sites decide identically.
-            const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3, T = (unsigned)p.T;
-            const unsigned f_lo = 16u * x * (fft_grid >> 3), f_hi = 16u * (x + 1) * (fft_grid >> 3);
+        // an XCD's sequence: [gate_batch gate blocks][their gate_batch x gate_run transform blocks], repeated
+        const unsigned GB = (unsigned)p.gate_batch, run = (unsigned)p.gate_run, per = GB * (run + 1u);
+        const unsigned jb = seq / per, rem = seq - jb * per;
+        const unsigned jg = jb * GB + rem;
+        if (rem < GB) {
+            const unsigned T = (unsigned)p.T;
+            const unsigned l_lo = jg * run < F ? jg * run : F, l_hi = l_lo + run < F ? l_lo + run : F;
+            const unsigned f_lo = 16u * (xcd * F + l_lo), f_hi = 16u * (xcd * F + l_hi);
             unsigned s_lo = (f_lo + T - 1) / T, s_hi = (f_hi + T - 1) / T;
             s_lo = s_lo < (unsigned)p.B ? s_lo : (unsigned)p.B;
             s_hi = s_hi < (unsigned)p.B ? s_hi : (unsigned)p.B;
-            const unsigned per = (gate_blocks >> 3);                              // gate blocks per XCD
-            const unsigned each = (s_hi - s_lo + per - 1) / (per ? per : 1);      // streams per gate block of this XCD
-            const unsigned b_end = s_lo + (j + 1) * each < s_hi ? s_lo + (j + 1) * each : s_hi;
-            for (unsigned b0 = s_lo + j * each; b0 < b_end; b0 += 4) {            // four streams per pass, workgroup-uniform
+            for (unsigned b0 = s_lo; b0 < s_hi; b0 += 4) {            // four streams per pass, workgroup-uniform
                 const SampleT* rows[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rows[r] = chunk_all + (size_t)(b0 + r < b_end ? b0 + r : b_end - 1) * n_chunk;
+                for (int r = 0; r < 4; ++r) rows[r] = chunk_all + (size_t)(b0 + r < s_hi ? b0 + r : s_hi - 1) * n_chunk;
                 float sums[4];
                 block_abs_sum_rows<SampleT, 4>(rows, n_chunk, sums);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned bs = b0 + r;
-                    if (bs < b_end) {
+                    if (bs < s_hi) {
                         if (tid == 0) vad_masks(sums[r], p.vad_thres, bs, p.restart, p.silent, p.reset);
                         carry_tail<SampleT>(p.carry + (size_t)bs * p.n_carry, p.n_carry, rows[r], n_chunk, p.next + (size_t)bs * p.n_next, p.n_next, tid, 256);
                     }
@@ -154,9 +157,10 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
             }
             return;
         }
+        local = jb * GB * run + (rem - GB);
     }
-    const unsigned bid = blockIdx.x - gate_blocks;
-    const unsigned blk = (bid & 7u) * (fft_grid >> 3) + (bid >> 3);
+    if (local >= F) return;                                            // surplus position of the last batch (uniform)
+    const unsigned blk = xcd * F + local;
     const unsigned f0 = blk * 16u;
     if (f0 >= total) return;                            // padding block of the rounded-up grid (uniform: before any barrier)
 #ifdef KWS_FE_TIMING       // tools/ubench/fe_phases.hip: s_memtime at the phase boundaries of every wave
@@ -384,14 +388,29 @@ static hipError_t launch_fft400_tiles(const FrontendParams& p, unsigned grid, hi
 hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st) {
     const long long total = (long long)B * p.T;        // < 2^31 (checked by the caller)
     const unsigned grid = (unsigned)(((total + 15) / 16 + 7) / 8 * 8);     // multiple of 8: the kernel's XCD-aware block map
-    if (!p.gate) return p.pcm_i16 ? launch_fft400_tiles<int16_t, false>(p, grid, st) : launch_fft400_tiles<float, false>(p, grid, st);
-    // gate blocks: kGateStreams streams each (four rows per pass), the same number on every XCD.  16 measured best at 4096 x 3600
-    // samples (tools/exp_gate_ab.sh: 1/2/4/8/16/24/32 -> 44.4/43.2/40.7/38.2/36.5/41.7/48.9 us per fused launch; 32.3 without the gate)
-    static const unsigned kGateStreams = [] { const char* e = getenv("KWS_FE_GATE_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 16u; }();
     FrontendParams q = p;
-    q.gate_blocks = (int)(8u * (((unsigned)B + 8u * kGateStreams - 1) / (8u * kGateStreams) + 1u));
-    return p.pcm_i16 ? launch_fft400_tiles<int16_t, true>(q, grid + (unsigned)q.gate_blocks, st)
-                     : launch_fft400_tiles<float, true>(q, grid + (unsigned)q.gate_blocks, st);
+    q.fft_blocks = (int)grid;
+    if (!p.gate) return p.pcm_i16 ? launch_fft400_tiles<int16_t, false>(q, grid, st) : launch_fft400_tiles<float, false>(q, grid, st);
+    // one gate block per gate_run transform blocks of an XCD's sequence: kGateStreams streams' worth of frames.  16 streams
+    // measured best at 4096 x 3600 samples (tools/exp_gate_ab.sh: 1/2/4/8/16/24/32 -> 44.4/43.2/40.7/38.2/36.5/41.7/48.9 us per
+    // fused launch; 32.3 without the gate)
+    static const unsigned kGateStreams = [] { const char* e = getenv("KWS_FE_GATE_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 16u; }();
+    const unsigned F = grid / 8;
+    unsigned run = (kGateStreams * (unsigned)p.T + 15u) / 16u;
+    run = run < 1u ? 1u : run;
+    q.gate_run = (int)run;
+    static const unsigned kGateBatch = [] { const char* e = getenv("KWS_FE_GATE_BATCH"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
+    // gate blocks per batch in an XCD's sequence; default: ALL of them first.  Interleaving them with their transform blocks
+    // (batches of 1 / 4 / 16) measured 43.7 / 48.5 / 41.8 us per launch against 36.7 with the gate blocks in front, and only the
+    // finest interleave with 8-stream blocks brought the L2-miss read traffic down to the algorithmic 67 MB (71 MB; in front:
+    // 94 MB -- the gate blocks pull 7 MB of rows per XCD through a 4 MB L2 before the transforms arrive; round 3: 140 MB).
+    q.gate_batch = (int)(kGateBatch ? kGateBatch : (F + run - 1) / run);
+    // per XCD: whole batches of (kGateBatch gate blocks + kGateBatch x run transform blocks); the last batch's surplus positions
+    // find no work and leave at once
+    const unsigned gb = (unsigned)q.gate_batch;
+    const unsigned batches = (F + gb * run - 1) / (gb * run);
+    const unsigned seq_len = batches * gb * (run + 1u);
+    return p.pcm_i16 ? launch_fft400_tiles<int16_t, true>(q, 8u * seq_len, st) : launch_fft400_tiles<float, true>(q, 8u * seq_len, st);
 }
 
 }  // namespace kws

@@ -1,6 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- numpy restatement of the deploy graph's audio front-end.
 
-PARITY UNPINNED: models/rnn_ctc.py:134-149 builds it from tf.spectral.rfft and librosa.filters.mel; neither
+PARITY PARTIAL (third-party fixture only: tests/golden/frontend_golden.npz from transformers.audio_utils -- the same Slaney mel
+bank and un-windowed magnitude STFT, tests/test_frontend_golden.py; not the reference run here).
+models/rnn_ctc.py:134-149 builds it from tf.spectral.rfft and librosa.filters.mel; neither
 TensorFlow nor librosa (era 0.5, not pinned by the reference) is installable here and the reference holds no
 fixture for this stage.  Restated from the call sites:
   utils/stft.py:27-81        tf_frame: num_frames = 1 + floor((N - 400)/160), no padding, no window

@@ -3,12 +3,15 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 The product (keyword_spotting_amd/) never imports anything under oracle/.
 
-PARITY UNPINNED for this file: the reference's GRU / dense / softmax arithmetic lives in
+PARITY PARTIAL for this file (third-party pins only, see the end of this paragraph): the reference's GRU / dense / softmax arithmetic lives in
 TensorFlow 1.x (`tensorflow.contrib.rnn.GRUCell`, `MultiRNNCell`, `dynamic_rnn`), a third-party
 dependency that is neither vendored in /root/reference nor version-pinned (no requirements file;
 era: TF 1.1 - 1.3, see utils/stft.py:26, models/rnn_ctc.py:182) and cannot be installed here.
 The reference holds no test or golden vector for this stage.  This module therefore restates the
-published TF-1.x GRUCell algorithm and is anchored on the reference's own call sites:
+published TF-1.x GRUCell algorithm and is anchored on the reference's own call sites; what pins it from
+outside is TensorFlow's own published unit-test constants for GRUCell / MultiRNNCell
+(tests/test_tf_published_kat.py: 0.175991, 0.156736, 0.13248) -- third-party evidence, not the reference
+run here, hence "partial" until tests/golden/make_gru_golden.py has run under TF 1.x:
 
   models/rnn_ctc.py:179-199  get_cell      -> plain GRUCell(num_units=H, activation=tanh)
   models/rnn_ctc.py:202-244  inference1    -> MultiRNNCell + dynamic_rnn, batch-major, initial_state tuple
