@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-layer kernel time (HIP events around each launch) against the frames per call: what a launch costs before its
-first frame and per frame after it.  B streams, fp32 resident kernels."""
+first frame and per frame after it.  usage: bench_tsweep.py [B] [fp32|f16x3]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from keyword_spotting_amd import get_config, weights
 from keyword_spotting_amd.rnn_ctc import DeployModel
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg = get_config()
+cfg = get_config(precision=sys.argv[2] if len(sys.argv) > 2 else "fp32")
 model = DeployModel(cfg, weights.init_weights(cfg))
 model.set_profiling(True)
 for T in (1, 2, 4, 8, 16, 22, 23, 44, 100, 300):
