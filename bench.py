@@ -28,16 +28,23 @@ PEAK_HBM_GBS = 8000.0
 
 
 def csrc_hash():
-    """sha1 over the kernel sources this build was made from; tools/prof.sh stores it next to every profile set
+    """sha1 over the kernel sources this build was made from (comments and whitespace stripped); tools/prof.sh stores it next to every profile set
     (profiles/<tag>_source_hash.txt) so that figures read back from a committed profile are dropped when the kernels
     have changed since."""
     import glob
     import hashlib
+    import re
     h = hashlib.sha1()
     d = os.path.join(ROOT, "keyword_spotting_amd", "csrc")
     for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        text = open(f, "r", errors="replace").read()
+        if not f.endswith("Makefile"):          # comments and layout do not change the kernels: code tokens only
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", " ", text)
+        else:
+            text = re.sub(r"#[^\n]*", " ", text)
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -4,8 +4,9 @@
 //
 // Every matmul operand is split into two fp16 numbers that together carry 22 mantissa bits,
 //     v = hi + 2^-11 lo,   hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (both round-to-nearest-even),
-// weights once at kws_create, activations on the fly (6 VALU instructions per register pair: v_cvt_pk_f16_f32,
-// 2 x v_cvt_f32_f16, v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32).  A product then needs THREE v_mfma_f32_16x16x32_f16
+// weights once at kws_create, activations on the fly (per pair of values: one v_cvt_pk_f16_f32 for hi, then per value a
+// v_mul_f32 by 2^11 and a v_fma_mixlo/hi_f16 that reads the fp16 half of hi and writes the rounded fp16 half of lo in place
+// -- bit-identical to subtract, scale, convert).  A product then needs THREE v_mfma_f32_16x16x32_f16
 // instead of eight v_mfma_f32_16x16x4_f32 of twice the duration (~51 matrix-pipe cycles per 32 k instead of 256):
 //     main += Wh Xh          lo += Wl Xh + Wh Xl          result = main + 2^-11 lo        (fp32 accumulators)
 // fp16 x fp16 products are exact in fp32; the dropped term Wl Xl 2^-22 is below fp32's own rounding of the product.  The
@@ -13,6 +14,8 @@
 // splits would need 3 + 3 pieces and six products for the same 24 bits; fp16's 11-bit pieces need two and three.
 // Range: |hidden| <= 1; weights must be < 64 in magnitude (kws_create checks); mel is pre-scaled by 2^-8 (and the
 // x-part weights of the first layer by 2^8, both exact), so |mel| up to 1.6e7 is represented and larger values saturate.
+// The exponent scales of the activations (sigmoid: -log2 e, tanh: 2 log2 e) are folded into the packed weights and biases,
+// so a pre-activation is the argument of v_exp_f32 as it stands.
 //
 // Weights are 4 bytes each again (hi + lo), so residency is the fp32 kernels': ONE LAYER per launch, the layers meet
 // through a seam in HBM -- here already split, in B-operand order, so the layer above reads its input ready to use.
@@ -23,13 +26,14 @@
 //                          4-operand register sets
 //
 // The frame loop is a static schedule.  Per frame a wave issues 147 (upper layers) / 111 (first layer) MFMAs of ~17
-// cycles and ~180 VALU instructions; an MFMA runs in the matrix pipe while the wave issues VALU work of its own, but issue
+// cycles and ~170 VALU instructions; an MFMA runs in the matrix pipe while the wave issues VALU work of its own, but issue
 // is in order, so the two only overlap when they ALTERNATE in the instruction stream.  The recurrence fixes a critical
 // chain  gates_h MFMAs -> r sigmoid -> r(.)h split -> LDS -> barrier -> cand_h MFMAs -> tanh, update, split -> LDS ->
 // barrier;  the next frame's x-part (72 / 36 MFMAs, independent of the recurrence) is the filler that is woven, one MFMA
-// per three VALU instructions, into the two activation phases and into the LDS round trips behind the barriers, and the u
-// sigmoid rides under the candidate MFMAs.  The weave is written out below with compile-time indices (streams G, C, X of
-// MFMAs; R, U, Cc of single VALU instructions) and pinned with sched_barrier(0) after every element; the compiler still
+// per three VALU instructions, into the two activation phases and into the LDS round trips around the barriers; the u
+// sigmoid rides under the candidate MFMAs, the x stream's setup reads and (first layer) the mel conversion under the gate
+// MFMAs.  The weave is written out below with compile-time indices (streams G, Cm, X of MFMAs; E of LDS reads; R, U, Cc, Mq
+// of single scalar VALU instructions) and pinned with sched_barrier(0) after every element; the compiler still
 // allocates registers, inserts the waitcnts and sees every hazard (builtin MFMAs only: with MFMA results in VGPRs --
 // csrc/Makefile builds this file with -amdgpu-mfma-vgpr-form, as gru_bf16.hip -- hipcc feeds operands pinned into AGPRs
 // ("+a" at load time) to the builtin directly, no v_accvgpr_read copies; checked in the ISA).
