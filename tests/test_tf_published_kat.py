@@ -130,6 +130,29 @@ def test_kws_step_returns_tensorflows_published_constants(n_mel, hidden, layers,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_mel,layers", [(40, 2), (40, 1), (60, 3), (32, 2)])
+@pytest.mark.parametrize("n_in", [2, 3])
+def test_f16x3_split_path_returns_the_published_constants_at_fp32_tolerance(n_mel, layers, n_in):
+    """precision="f16x3" (fp16 matrix pipe on split operands) has to meet the fp32 kernels' tolerance, 1e-6 here: 0.5, 1.0 and
+    0.1 split exactly or to 2^-22, the rest is the activations' fp32 arithmetic."""
+    w = embedded(n_mel, 128, n_in, layers)
+    mel, st0 = embedded_inputs(n_mel, 128, n_in, layers, 19)
+    m = _model(n_mel, 128, layers, w, "auto", "f16x3")
+    r = m.forward(torch.from_numpy(mel), torch.from_numpy(st0))
+    st = r["state"].cpu().numpy()
+    first = KAT_2 if n_in == 2 else KAT_3
+    assert not st[:, :, 2:].any()
+    np.testing.assert_allclose(st[0, :, :2], first, atol=TF_TOL)
+    x = first
+    for l in range(1, layers):
+        x = G.gru_cell(np.full((1, 2), x), np.full((1, 2), 0.1), tf_cell(2), np.float64)[0, 0]
+        np.testing.assert_allclose(st[l, :, :2], x, atol=TF_TOL)
+    if layers >= 2 and n_in == 2:
+        np.testing.assert_allclose(st[1, :, :2], KAT_L1, atol=TF_TOL)
+    np.testing.assert_allclose(r["logits"].cpu().numpy()[:, 0, :2], x, atol=TF_TOL)
+
+
+@pytest.mark.gpu
 def test_bf16_and_int8_variants_on_the_published_case():
     """0.5 and 1.0 are exact in bf16 / int8; what is left is the rounding of the activations (reported, loose)."""
     w = embedded(40, 128, 2, 2)
