@@ -5,7 +5,8 @@ front-end is made of (models/rnn_ctc.py:134-149): a Slaney-scale, area-normalise
 
 librosa and TensorFlow cannot be installed here; `transformers.audio_utils` (installed in this image, 5.15) implements
 the same published algorithms -- mel_filter_bank(norm="slaney", mel_scale="slaney") is librosa's htk=False/norm=1 bank
--- and was written by neither the reference's author nor this repo's.  It is NOT the reference run here: the front-end
+-- and was written by neither the reference's author nor this repo's; the un-windowed magnitude spectrum is taken a second
+time from scipy.signal.stft (boxcar window, no boundary extension).  It is NOT the reference run here: the front-end
 stays "parity partial"  until tests/golden/make_gru_golden.py case D runs under TF 1.x + librosa.
 
     python tests/golden/make_frontend_golden.py            (build container; writes the .npz next to this file)
@@ -13,6 +14,8 @@ stays "parity partial"  until tests/golden/make_gru_golden.
 import os
 
 import numpy as np
+import scipy
+import scipy.signal
 from transformers import audio_utils as A
 import transformers
 
@@ -33,9 +36,17 @@ def melspec(pcm, fb):
     return s.T
 
 
+def linspec_scipy(pcm):
+    """[T, 201] float64 magnitude spectrum from a SECOND third-party implementation: scipy.signal.stft with a boxcar window,
+    no boundary extension, no padding (it scales by 1 / sum(window) = 1 / 400, undone here)."""
+    _, _, z = scipy.signal.stft(np.asarray(pcm, np.float64), fs=SR, window="boxcar", nperseg=NFFT, noverlap=NFFT - HOP, nfft=NFFT,
+                                boundary=None, padded=False, return_onesided=True)
+    return np.abs(z).T * NFFT
+
+
 def main():
     rng = np.random.default_rng(20174)
-    out = {"transformers_version": np.array(transformers.__version__)}
+    out = {"transformers_version": np.array(transformers.__version__), "scipy_version": np.array(scipy.__version__)}
     for n_mels in (40, 60):
         # the deploy graph holds the bank as a float32 constant (tf.constant of librosa's float array, :139-141)
         out["basis_%d" % n_mels] = bank(n_mels)
@@ -52,6 +63,7 @@ def main():
     for name, pcm in cases.items():
         pcm = pcm.astype(np.float32)                                           # what the placeholder is fed
         out["pcm_" + name] = pcm
+        out["lin_" + name] = linspec_scipy(pcm)
         for n_mels in (40, 60):
             fb32 = out["basis_%d" % n_mels].astype(np.float32).astype(np.float64)
             out["mel%d_%s" % (n_mels, name)] = melspec(pcm, fb32)
