@@ -10,7 +10,8 @@ era: TF 1.1 - 1.3, see utils/stft.py:26, models/rnn_ctc.py:182) and cannot be in
 The reference holds no test or golden vector for this stage.  This module therefore restates the
 published TF-1.x GRUCell algorithm and is anchored on the reference's own call sites; what pins it from
 outside is TensorFlow's own published unit-test constants for GRUCell / MultiRNNCell
-(tests/test_tf_published_kat.py: 0.175991, 0.156736, 0.13248) -- third-party evidence, not the reference
+(tests/test_tf_published_kat.py: 0.175991, 0.156736, 0.13248) and torch.nn.GRU over whole sequences on the weight
+family where the two cells coincide (tests/test_torch_gru_pin.py) -- third-party evidence, not the reference
 run here, hence "partial" until tests/golden/make_gru_golden.py has run under TF 1.x:
 
   models/rnn_ctc.py:179-199  get_cell      -> plain GRUCell(num_units=H, activation=tanh)
