@@ -45,8 +45,16 @@ def torch_stack(w, n_mel, hidden):
     fc_w, fc_b = torch.from_numpy(w["Wfc"].astype(np.float64)), torch.from_numpy(w["bfc"].astype(np.float64))
 
     @torch.no_grad()
-    def run(mel, state):
-        out, hn = gru(torch.from_numpy(np.asarray(mel, np.float64)), torch.from_numpy(np.asarray(state, np.float64)))
+    def run(mel, state, lens=None):
+        x, h0 = torch.from_numpy(np.asarray(mel, np.float64)), torch.from_numpy(np.asarray(state, np.float64))
+        if lens is None:
+            out, hn = gru(x, h0)
+        else:
+            # packed sequences: rows past a stream's length come back as zeros and h_n is the state at its last valid frame --
+            # what dynamic_rnn(sequence_length=...) does (models/rnn_ctc.py:238-243)
+            pk = torch.nn.utils.rnn.pack_padded_sequence(x, torch.as_tensor(lens, dtype=torch.int64), batch_first=True, enforce_sorted=False)
+            out, hn = gru(pk, h0)
+            out, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True, total_length=x.shape[1])
         return (out @ fc_w + fc_b).numpy(), hn.numpy()
     return run
 
@@ -61,6 +69,19 @@ def test_oracle_equals_torch_gru_on_the_common_family(n_mel, hidden, layers):
         got_l, got_s = fwd(w, mel, st0, dtype=np.float64)
         np.testing.assert_allclose(got_l, want_l, atol=1e-11)
         np.testing.assert_allclose(got_s, want_s, atol=1e-12)
+
+
+def test_sequence_lengths_match_torch_packed_sequences():
+    """dynamic_rnn(sequence_length): zero output rows (logits = bias) and state copy-through past a stream's length."""
+    w = diag_candidate_weights(40, 128, 2, 6, seed=91)
+    b, t = 9, 30
+    mel = G.synthetic_mel(b, t, 40, seed=92)
+    st0 = (0.4 * np.random.default_rng(93).standard_normal((2, b, 128))).astype(np.float32)
+    lens = np.array([30, 1, 17, 29, 2, 30, 8, 15, 23])
+    want_l, want_s = torch_stack(w, 40, 128)(mel, st0, lens)
+    got_l, got_s = G.gru_forward(w, mel, st0, seq_len=lens, dtype=np.float64)
+    np.testing.assert_allclose(got_l, want_l, atol=1e-11)
+    np.testing.assert_allclose(got_s, want_s, atol=1e-12)
 
 
 def test_the_two_cells_really_differ_off_the_family():
@@ -102,3 +123,22 @@ def test_kws_step_equals_torch_gru_over_a_300_frame_sequence(n_mel, hidden, laye
     assert np.abs(r["state"].cpu().numpy() - want_s).max() < 1e-4
     sm = torch.softmax(torch.from_numpy(want_l), -1).numpy()
     assert np.abs(r["softmax"].cpu().numpy() - sm).max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel,precision", [("resident", "fp32"), ("generic", "fp32"), ("auto", "f16x3")])
+def test_kws_step_sequence_lengths_equal_torch_packed_sequences(kernel, precision):
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    w = diag_candidate_weights(40, 128, 2, 6, seed=94)
+    b, t = 37, 41
+    mel = G.synthetic_mel(b, t, 40, seed=95)
+    rng = np.random.default_rng(96)
+    st0 = (0.4 * rng.standard_normal((2, b, 128))).astype(np.float32)
+    lens = rng.integers(1, t + 1, b)
+    lens[:3] = [t, 1, 2]
+    want_l, want_s = torch_stack(w, 40, 128)(mel, st0, lens)
+    m = DeployModel(get_config(precision=precision), w, kernel=kernel)
+    r = m.forward(torch.from_numpy(mel), torch.from_numpy(st0), seq_len=torch.from_numpy(lens.astype(np.int32)))
+    assert np.abs(r["logits"].cpu().numpy() - want_l).max() < 1e-4
+    assert np.abs(r["state"].cpu().numpy() - want_s).max() < 1e-4
