@@ -5,7 +5,11 @@ The two cells differ in ONE place: TF-1.x GRUCell (the reference's cell, models/
 the candidate's recurrent matmul, c = tanh(x Wx + (r (.) h) Wh + b); PyTorch / cuDNN apply it AFTER, n = tanh(x Wx + b + r (.) (h Wh)).
 For a DIAGONAL Wh the two coincide (r (.) (h D) = (r (.) h) D); everything else -- gate order, gate biases, the update
 h' = u h + (1 - u) c, layer stacking, state carry over the sequence, the dense layer -- is exercised with full random weights.
-(The reset-before-matmul rule itself is what TensorFlow's published constants pin: tests/test_tf_published_kat.py.)
+The reset-before-matmul rule itself is the ONE element no third-party number available here distinguishes: TensorFlow's published
+constants (tests/test_tf_published_kat.py) use two symmetric units, for which both conventions give 0.175991.  It rests on the TF-1.x
+source as restated in SURVEY.md R4 / oracle/gru_oracle.py (`candidate = linear([inputs, r * state])`) and on the hand-computed
+asymmetric case tests/test_oracle_gru.py::test_gate_order_and_reset_before_matmul; test_the_two_cells_really_differ... below shows
+that the kernels do NOT follow the PyTorch/cuDNN convention.
 
 Not the reference run here, so the GRU stage stays "parity partial" (DESIGN.md section 5)."""
 import numpy as np
@@ -85,8 +89,8 @@ def test_sequence_lengths_match_torch_packed_sequences():
 
 
 def test_the_two_cells_really_differ_off_the_family():
-    """With a full candidate-recurrent matrix torch.nn.GRU is NOT the reference's cell: the pin above is not vacuous, and an
-    implementation that applied the reset gate cuDNN-style would be caught by the published-constants test instead."""
+    """With a full candidate-recurrent matrix torch.nn.GRU is NOT the reference's cell (reset after vs before the matmul): the
+    oracle follows TF's convention, and the pin above is not vacuous."""
     w = G.random_weights(40, 128, 1, 6, seed=74)
     mel = G.synthetic_mel(2, 20, 40, seed=75)
     st0 = np.zeros((1, 2, 128), np.float32)
