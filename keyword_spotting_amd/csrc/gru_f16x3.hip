@@ -173,6 +173,38 @@ gru_layer_f16x3(const GruF16Params p) {
     auto wload = [&](int j, int q, int c, int hl) { return as_f16x8(wt_tab[((((2 * w + j) * 3 + q) * KC + c) * 2 + hl) * 64 + lane]); };
     f16x8 wh[2][3][4][2];          // recurrent part: AGPRs
     f16x8 wx[2][3][KX][2];         // x-part: by x_place
+    // all loads first, the "+a" pins afterwards: a pin right behind its load makes the compiler wait for that load before it
+    // issues the next one (64 serial L2 round trips: +10 us per launch, a sixth of a 22-frame call)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        static_for<0, 3>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) wh[j][q][m][hl] = wload(j, q, KX + m, hl);
+            static_for<0, KX>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                if constexpr (x_place<KX, FIRST>(q, c) != kInLds) {
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl) wx[j][q][c][hl] = wload(j, q, c, hl);
+                }
+            });
+        });
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        static_for<0, 3>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            static_for<0, KX>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                if constexpr (x_place<KX, FIRST>(q, c) == kInLds) {
+                    constexpr int k = lds_group<KX, FIRST>(q, c);
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl)
+                        wul[((w * NG + k) * 4 + j * 2 + hl) * 64 + lane] = wt_tab[((((2 * w + j) * 3 + q) * KC + c) * 2 + hl) * 64 + lane];
+                }
+            });
+        });
 #pragma unroll
     for (int j = 0; j < 2; ++j)
         static_for<0, 3>([&](auto q_) {
@@ -181,20 +213,16 @@ gru_layer_f16x3(const GruF16Params p) {
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl) {
-                    wh[j][q][m][hl] = wload(j, q, KX + m, hl);
-                    asm volatile("" : "+a"(wh[j][q][m][hl]));
+                    f16x8& op = wh[j][q][m][hl];
+                    asm volatile("" : "+a"(op));
                 }
             static_for<0, KX>([&](auto c_) {
                 constexpr int c = decltype(c_)::value;
-                constexpr int place = x_place<KX, FIRST>(q, c);
+                if constexpr (x_place<KX, FIRST>(q, c) == kInAgpr) {
 #pragma unroll
-                for (int hl = 0; hl < 2; ++hl) {
-                    if constexpr (place == kInLds) {
-                        constexpr int k = lds_group<KX, FIRST>(q, c);
-                        wul[((w * NG + k) * 4 + j * 2 + hl) * 64 + lane] = wt_tab[((((2 * w + j) * 3 + q) * KC + c) * 2 + hl) * 64 + lane];
-                    } else {
-                        wx[j][q][c][hl] = wload(j, q, c, hl);
-                        if constexpr (place == kInAgpr) asm volatile("" : "+a"(wx[j][q][c][hl]));
+                    for (int hl = 0; hl < 2; ++hl) {
+                        f16x8& op = wx[j][q][c][hl];          // (named: clang does not capture a variable that only an asm operand names)
+                        asm volatile("" : "+a"(op));
                     }
                 }
             });
@@ -298,10 +326,13 @@ gru_layer_f16x3(const GruF16Params p) {
         fl.mel = splat4(0.f);
         fl.hi = fl.lo = (u32x4){0u, 0u, 0u, 0u};
         __syncthreads();              // LDS tables / previous group's readers
-        fetch(fl, 0);
-        commit(fl, 0);                // x(0) -> slot 0
-        fetch(fl, 1);
-        commit(fl, 1);                // x(1) -> slot 1
+        {
+            XF f1 = fl;
+            fetch(fl, 0);             // both requests in flight together: two serial memory round trips cost ~2 us per launch
+            fetch(f1, 1);
+            commit(fl, 0);            // x(0) -> slot 0
+            commit(f1, 1);            // x(1) -> slot 1
+        }
         fetch(fl, 2);                 // x(2): committed during frame 0
         __syncthreads();
 
