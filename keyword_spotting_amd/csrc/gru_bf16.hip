@@ -515,10 +515,16 @@ gru_stack_bf16_ls(const GruBf16Params p) {
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
-                for (int c = 0; c < KC0; ++c) {
+                for (int c = 0; c < KC0; ++c)
                     w0[j][q][c] = as_bf16x8(reinterpret_cast<const u32x4*>(p.w[0])[(((2 * w + j) * 3 + q) * KC0 + c) * 64 + lane]);
-                    asm volatile("" : "+a"(w0[j][q][c]));
-                }
+        // all loads first, the AGPR pins afterwards: a pin right behind its load makes the compiler wait for that load before it
+        // issues the next one (36 serial L2 round trips per launch)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < KC0; ++c) asm volatile("" : "+a"(w0[j][q][c]));
         asm volatile("s_nop 7" ::: "memory");
         // mel: wave w fetches streams 4w..4w+3 (one dwordx4 per lane), rounds to bf16, scatters into the B-operand image
         const int XQ = p.I / 4;
@@ -642,10 +648,14 @@ gru_stack_bf16_ls(const GruBf16Params p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int c = 0; c < KC1; ++c) {
+                for (int c = 0; c < KC1; ++c)
                     w1[j][q][c] = as_bf16x8(reinterpret_cast<const u32x4*>(p.w[1])[(((2 * w + j) * 3 + q) * KC1 + c) * 64 + lane]);
-                    asm volatile("" : "+a"(w1[j][q][c]));
-                }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < KC1; ++c) asm volatile("" : "+a"(w1[j][q][c]));
         asm volatile("s_nop 7" ::: "memory");
         const bf16x8 wfc = as_bf16x8(reinterpret_cast<const u32x4*>(p.wfc)[w * 64 + lane]);
         f32x4 bfc4 = splat4(0.f);
