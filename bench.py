@@ -430,6 +430,8 @@ def main(argv=None, model_factory=None):
     ap.add_argument("--sustain-seconds", type=float, default=10.0, help="length of the sustained-load run after the timed region")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the "
                     "multi-process path on a box with fewer GPUs than ranks")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at one rank: runs the RCCL "
+                    "init / barrier / reduction / gather code of the N > 1 path on a single-GPU box")
     args = ap.parse_args(argv)
     stub = model_factory is not None
 
@@ -453,9 +455,12 @@ def main(argv=None, model_factory=None):
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

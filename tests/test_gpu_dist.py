@@ -2,7 +2,10 @@
 torch.distributed.run, rendezvous on 127.0.0.1) drive two instances of libkws_amd.so.  The box has one GPU, so both ranks
 land on cuda:0 (local_rank % device_count) and the process group is gloo -- what is exercised is the launcher, the
 rank/device plumbing, two library instances side by side, the barriers around the timed region and the SUM/MAX
-reduction, i.e. everything of BASELINE configs[3] except RCCL itself and the other seven GPUs."""
+reduction, i.e. everything of BASELINE configs[3] except RCCL itself and the other seven GPUs.  RCCL itself is initialised and
+used by the last test: one rank under torch.distributed.run with the nccl backend (--force-dist), so that the opening and
+closing barriers, the SUM/MAX reductions and the per-rank gather of the N > 1 path have run over RCCL on this image at
+least once before an 8-GPU node sees them."""
 import json
 import os
 import subprocess
@@ -43,6 +46,27 @@ def test_two_ranks_on_one_gpu_drive_the_hip_library_and_aggregate():
           % (two["value"] / 1e6, one["value"] / 1e6, ratio))
     assert 0.85 < ratio < 1.15, (two["value"], one["value"])          # measured 0.98: the two processes' kernels share the chip
     assert two["ms_per_step"] > 0 and abs(two["value"] - 2 * 1024 * 300 / (two["ms_per_step"] * 1e-3)) < 1e-6 * two["value"]
+
+
+def test_rccl_process_group_path_at_one_rank():
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--sustain-seconds", "0", "--force-dist"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and len(line["per_rank"]) == 1 and line["distinct_devices"] == 1
+    assert line["per_rank"][0]["device"] == "cuda:0" and line["value"] > 1e8
 
 
 @pytest.mark.parametrize("world,precision", [(2, "fp32"), (3, "fp32"), (2, "bf16")])
