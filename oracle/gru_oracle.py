@@ -245,7 +245,7 @@ def octbit_layer_is_quantised(layer):
         "model/drnn/multi_rnn_cell/cell_%d/gru_cell/gates/MatMul" % layer)
 
 
-def gru_forward_octbit(w, mel, state=None, seq_len=None):
+def gru_forward_octbit(w, mel, state=None, seq_len=None, saturate=True):
     from oracle import octbit_oracle as Q
     f32 = np.float32
     mel = np.asarray(mel, f32)
@@ -272,9 +272,9 @@ def gru_forward_octbit(w, mel, state=None, seq_len=None):
                 hn = gru_cell(x, h[l], lay, f32)
             else:
                 (gq, gs, gb), (cq, cs, cb) = qw[l]["g"], qw[l]["c"]
-                g = _sigmoid((Q.octbit_rows(np.concatenate([x, h[l]], 1), gq, gs, gb) + lay["bg"].astype(f32)).astype(f32))
+                g = _sigmoid((Q.octbit_rows(np.concatenate([x, h[l]], 1), gq, gs, gb, saturate=saturate) + lay["bg"].astype(f32)).astype(f32))
                 r, u = g[:, :hdim], g[:, hdim:]
-                c = np.tanh((Q.octbit_rows(np.concatenate([x, (r * h[l]).astype(f32)], 1), cq, cs, cb)
+                c = np.tanh((Q.octbit_rows(np.concatenate([x, (r * h[l]).astype(f32)], 1), cq, cs, cb, saturate=saturate)
                              + lay["bc"].astype(f32)).astype(f32))
                 hn = (u * h[l] + (f32(1.0) - u) * c).astype(f32)
             h[l] = np.where(live, hn, h[l])
@@ -283,7 +283,7 @@ def gru_forward_octbit(w, mel, state=None, seq_len=None):
     if Q.default_octbit_matmul_name_check("model/MatMul"):
         fq, fs, fb = Q.octize_weight_int8_signed(w["Wfc"])
         # pad the class rows are not needed: N is free, only K % 64 == 0 is required
-        flat = Q.octbit_rows(top.reshape(b * t_len, hdim), fq, fs, fb, groups=np.repeat(np.arange(b), t_len))
+        flat = Q.octbit_rows(top.reshape(b * t_len, hdim), fq, fs, fb, groups=np.repeat(np.arange(b), t_len), saturate=saturate)
     else:
         flat = top.reshape(-1, hdim) @ w["Wfc"].astype(f32)
     logits = (flat + w["bfc"].astype(f32)).astype(f32).reshape(b, t_len, -1)

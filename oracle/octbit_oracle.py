@@ -62,7 +62,7 @@ def octbit_matmul_ref(x, wq, scale_w, bias):
     return out
 
 
-def octbit_rows(x, wq, scale_w, bias, groups=None):
+def octbit_rows(x, wq, scale_w, bias, groups=None, saturate=True):
     """octbit/octbit_mat_mul_op.cc:90-181 vectorised over R independent calls.
 
     x [R,K]; rows sharing a value in `groups` ([R] ints) form ONE op call (its `[A,K]` input: one
@@ -70,7 +70,9 @@ def octbit_rows(x, wq, scale_w, bias, groups=None):
     batch 1, so each GRU matmul sees A == 1).  The four i32 SSE lanes (:141-175) add up exactly in float
     (|sum| < 2^24), so the lane fold is not modelled separately here -- octbit_matmul_ref keeps it.
     An all-zero call has bscale == 0 and divides 0/0 in the reference; its output is defined here as 0
-    (what x86 yields: the NaN casts to q == 0, and the output scale is 0)."""
+    (what x86 yields: the NaN casts to q == 0, and the output scale is 0).
+    saturate=False drops _mm_maddubs_epi16's int16 clamp of the pair sums: NOT the reference's arithmetic, only the
+    what-if of tests/test_oracle_octbit.py (how much of the int8 error is the clamp, how much the 8 bits)."""
     x = np.ascontiguousarray(x, np.float32)
     r_rows, k = x.shape
     n = wq.shape[0]
@@ -91,7 +93,7 @@ def octbit_rows(x, wq, scale_w, bias, groups=None):
     q = q.astype(np.int64).astype(np.uint8).astype(np.int32)
     wt = np.ascontiguousarray(wq.T).astype(np.int32)                    # [K, N]
     pair = q[:, 0::2, None] * wt[None, 0::2, :] + q[:, 1::2, None] * wt[None, 1::2, :]
-    acc = np.clip(pair, -32768, 32767).sum(axis=1)                      # [R, N] exact
+    acc = (np.clip(pair, -32768, 32767) if saturate else pair).sum(axis=1)     # [R, N] exact
     o = acc.astype(np.float32) - np.where(signed[:, None], np.asarray(bias, np.float32)[None, :], np.float32(0))
     scale = (np.float32(scale_w) * bscale).astype(np.float32)
     return (o.astype(np.float32) * scale[:, None]).astype(np.float32)

@@ -127,3 +127,24 @@ def test_int8_gru_oracle_structure():
     np.testing.assert_array_equal(sm[:, 2], np.zeros((2, 128), np.float32))
     # (numpy's BLAS rounds the fp32 layer 0 differently for batch 1 and 3: last-bit input changes, rare q flips)
     np.testing.assert_allclose(sm[:, 1], G.gru_forward_octbit(w, mel[1:2, :4])[1][:, 0], atol=2e-3)
+
+
+def test_what_an_exact_accumulating_int8_mode_would_buy():
+    """an explicitly NON-reference int8 mode without _mm_maddubs_epi16's pair saturation
+    (octbit/octbit_mat_mul_op.cc:149-170), e.g. on v_mfma_i32_16x16x64_i8.  Measured on the oracle before building anything:
+    dropping the clamp removes >90 % of the int8-vs-fp32 logit error on glorot-uniform weights (64 streams x 300 frames:
+    mean |dlogit| 0.352 -> 0.026, frames with the fp32 word 76 % -> 98 %), but 8-bit activations still leave NO stream with the
+    fp32 word sequence over 300 frames, where the bf16 stack (2 G frames/s) keeps 22-38 % and the f16x3 path (1 G frames/s)
+    all of them.  Its matmuls would be three times cheaper than the saturating emulation, the per-call range / quantise /
+    rescale VALU work and the fp32 cell_0 (octbit_graph.py:218-225 leaves it unquantised) would not: slower than bf16 AND less
+    accurate, so the mode is not built.  This test keeps the numbers that decision rests on."""
+    from oracle import gru_oracle as G
+    w = G.random_weights(40, 128, 2, 6, seed=0)
+    mel = np.abs(np.random.default_rng(5).standard_normal((12, 80, 40)).astype(np.float32)) * 2
+    ref, _ = G.gru_forward(w, mel)
+    sat, _ = G.gru_forward_octbit(w, mel)
+    exact, _ = G.gru_forward_octbit(w, mel, saturate=False)
+    e_sat, e_exact = np.abs(sat - ref).mean(), np.abs(exact - ref).mean()
+    assert e_sat > 0.15 and e_exact < 0.06 and e_exact < 0.25 * e_sat, (e_sat, e_exact)
+    word = lambda l: l[..., 1:-1].argmax(-1)                     # the class ctc_decode2's frame rule would name
+    assert (word(exact) == word(ref)).mean() >= (word(sat) == word(ref)).mean()
