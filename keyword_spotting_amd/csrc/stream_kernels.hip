@@ -10,9 +10,9 @@
 
 namespace kws {
 
-// One wave per stream, all 64 lanes busy: the per-frame rule, the ring's trip through LDS, the FIFO concatenation,
-// the change-point compaction (ballot + popcount keeps the order) and the label match (every start position in
-// parallel).  ctc_predict only asks whether the label occurs in the emitted words, so "first hit wins" in the
+// One wave per stream, all 64 lanes busy: the per-frame rule, the ring's trip through LDS, the walk over the window in
+// FIFO order with the change-point compaction (ballot + popcount keeps the order) and the label match (every start
+// position in parallel).  ctc_predict only asks whether the label occurs in the emitted words, so "first hit wins" in the
 // reference's loop and "any hit" here are the same decision.  (A lane-0 replay of the window took 61 us for 4096
 // streams: ~400 cycles per frame of single-lane, latency-bound code.)
 __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
@@ -20,8 +20,7 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
     const int NQ = p.nq, TM = p.tmax, C = p.C;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* ring = lds;                    // [NQ][TM] words of this stream
-    unsigned char* seq = ring + NQ * TM;          // the window concatenated in FIFO order
-    unsigned char* emit = seq + NQ * TM;          // emitted words (1-based), compacted
+    unsigned char* emit = ring + NQ * TM;         // emitted words (1-based), compacted in order
     int head = p.head[b], count = p.count[b];
     if (p.clear_before && p.clear_before[b]) { head = 0; count = 0; }
     // add(): drop the oldest chunk when full (utils/queue.py:26-32)
@@ -39,20 +38,12 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
             if (row[c] > best) { best = row[c]; arg = c - 1; }
         gring[slot * TM + t] = (int8_t)(best > p.thres ? arg : -1);
     }
-    // chunk lengths in FIFO order: lane q holds chunk q (NQ <= 64, checked by kws_window_create), then an inclusive
-    // prefix over the whole wave
+    // chunk lengths in FIFO order: lane q holds chunk q (NQ <= 64, checked by kws_window_create)
     int len = 0;
     if (lane < count) {
         const int sl = (head + lane) % NQ;
         len = sl == slot ? p.T : p.lens[b * NQ + sl];
     }
-    int incl = len;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-    }
-    const int total = __shfl(incl, count - 1);
     // ring -> LDS, 16 bytes per lane per trip (the new chunk's bytes come from the stores above: same wave, so
     // wait for them and read back through the cache)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -61,26 +52,33 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
     for (int i = lane; i < nvec; i += 64)
         reinterpret_cast<uint4*>(ring)[i] = reinterpret_cast<const uint4*>(gring)[i];
     __syncthreads();
-    // concatenate (detector.py:197): chunk q goes to seq[off_q ...)
-    for (int q = 0; q < count; ++q) {
-        const int lq = __shfl(len, q), off = __shfl(incl, q) - lq, sl = (head + q) % NQ;
-        for (int t = lane; t < lq; t += 64) seq[off + t] = ring[sl * TM + t];
-    }
-    __syncthreads();
-    // emit on word changes (utils/prediction.py:76-80), compacted in order
+    // The window in FIFO order (detector.py:197) is walked over the PADDED grid j = q TM + t, 64 cells per trip, without copying it
+    // together first: a cell is live if t < len_q; a live cell emits its word on a change against the live cell before it
+    // (utils/prediction.py:76-80) -- the nearest live lane below (ballot + bit scan + one cross-lane read), or the last live
+    // cell of the trips before (a wave-uniform carry).  Emitted words are compacted in order (ballot + popcount).  (A loop over
+    // the queued chunks that first concatenated them in LDS took 0.5 us per chunk: 5 us of this kernel's 10 with a full window.)
     int n_emit = 0;
-    for (int base = 0; base < total; base += 64) {
-        const int pos = base + lane;
-        bool flag = false;
-        int wd = -1;
-        if (pos < total) {
-            wd = (int)(signed char)seq[pos];
-            const int pw = pos > 0 ? (int)(signed char)seq[pos - 1] : -1;
-            flag = wd >= 0 && wd != pw;
-        }
+    int carry_word = -1;
+    const float inv_tm = 1.0f / (float)TM;
+    const int cells = count * TM;
+    for (int base = 0; base < cells; base += 64) {
+        const int j = base + lane;
+        const int q = (int)(((float)j + 0.5f) * inv_tm), t = j - q * TM;        // exact: j < 64 * 4096
+        const int lq = __shfl(len, q < count ? q : 0);
+        const bool livec = j < cells && t < lq;
+        int sl = head + q;
+        sl -= sl >= NQ ? NQ : 0;
+        const int wd = livec ? (int)(signed char)ring[sl * TM + t] : -1;
+        const unsigned long long lv = __builtin_amdgcn_ballot_w64(livec);
+        const unsigned long long below = lv & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __builtin_clzll(below) : lane;
+        const int pv = __shfl(wd, src);
+        const int pw = below ? pv : carry_word;
+        const bool flag = livec && wd >= 0 && wd != pw;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
         if (flag) emit[n_emit + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned char)(wd + 1);
         n_emit += __builtin_popcountll(m);
+        if (lv) carry_word = __shfl(wd, 63 - __builtin_clzll(lv));
     }
     __syncthreads();
     // ctc_predict (utils/prediction.py:111-118): is the label a substring of the emitted words?
@@ -109,7 +107,7 @@ __global__ void window_reset_kernel(int B, int* head, int* count) {
 }
 
 hipError_t launch_window_step(const WindowParams& p, hipStream_t st) {
-    hipLaunchKernelGGL(window_step_kernel, dim3(p.B), dim3(64), (size_t)3 * p.nq * p.tmax, st, p);
+    hipLaunchKernelGGL(window_step_kernel, dim3(p.B), dim3(64), (size_t)2 * p.nq * p.tmax, st, p);
     return hipGetLastError();
 }
 hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st) {
