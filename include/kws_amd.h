@@ -202,8 +202,8 @@ int kws_frontend_run_carry(kws_frontend_handle h, const float* carry, int n_carr
 int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host);
 
 /* Device-side decode window of the streaming loop (detector.py:122,168-209; utils/queue.py): per stream a
- * bounded FIFO of up to `max_chunks` (1..64) softmax chunks (each <= max_frames frames; 3 * max_chunks *
- * round_up(max_frames, 16) bytes must fit 64 KiB, else KWS_ERR_UNSUPPORTED).  ctc_decode2's per-frame rule
+ * bounded FIFO of up to `max_chunks` (1..64) softmax chunks (each <= max_frames frames; 2 * max_chunks *
+ * round_up(max_frames, 16) bytes must fit 48 KiB, else KWS_ERR_UNSUPPORTED).  ctc_decode2's per-frame rule
  * (argmax over classes 1..C-2, strictly above `thres`) is a function of the frame alone, so the window stores each
  * frame's word rather than its softmax row; `thres` is therefore fixed per handle.  kws_window_step, per stream:
  *   clear_before[b] != 0 -> empty the window first (silence: detector.py:171-177);

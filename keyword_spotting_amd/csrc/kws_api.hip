@@ -1147,8 +1147,8 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres,
     // window_step_kernel: one lane per queued chunk and two byte images of the window (ring, emitted words) in LDS
     if (max_chunks > 64)
         return fail(KWS_ERR_UNSUPPORTED, "max_chunks=%d unsupported (1..64; the reference uses SimpleQueue(15), detector.py:122)", max_chunks);
-    if ((size_t)2 * max_chunks * ((max_frames + 15) & ~15) > 64 * 1024 || (size_t)max_chunks * ((max_frames + 15) & ~15) > 32768)
-        return fail(KWS_ERR_UNSUPPORTED, "window of %d chunks x %d frames exceeds the 64 KiB of LDS the kernel stages it in", max_chunks, max_frames);
+    if ((size_t)2 * max_chunks * ((max_frames + 15) & ~15) > 48 * 1024)
+        return fail(KWS_ERR_UNSUPPORTED, "window of %d chunks x %d frames exceeds the 48 KiB of LDS the kernel stages it in", max_chunks, max_frames);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(KWS_ERR_NO_DEVICE, "no HIP device visible");
     kws_window* wnd = new (std::nothrow) kws_window();

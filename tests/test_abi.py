@@ -98,7 +98,7 @@ def test_product_never_imports_the_oracle():
 
 
 def test_window_shape_limits_are_rejected_before_any_device_work():
-    """kws_window_create: one lane per queued chunk (<= 64) and the window staged in <= 64 KiB of LDS."""
+    """kws_window_create: one lane per queued chunk (<= 64) and the window staged in <= 48 KiB of LDS."""
     from keyword_spotting_amd import _lib
     lib = _lib.load()
     h = ctypes.c_void_p()
