@@ -94,10 +94,9 @@ constexpr int kSpecRows = 208;                 // spectrum rows (bins 0..200 + z
 // 52 MFMAs per 16 frames for 40 filters where the dense product takes 156.  Wave m = tile m.
 // 26 KiB of LDS per workgroup (the spectrum reuses the transpose planes): six workgroups = 24 waves per CU.
 // SampleT: float samples, or int16 PCM as the sound card delivers it (detector.py:40-43,74-79: scaled by 2^-15 on load --
-// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along in the same launch as
-// extra "gate" workgroups in front of the transform blocks: vad sum of a stream's new samples (the masks silent / reset) and
-// its next sample carry, taken on the XCD that transforms that stream, so the PCM is fetched from HBM once (r3: the gate of
-// stream k sat in transform workgroup k, on another XCD -- 1.7x the algorithmic read traffic and +9 us per launch).
+// read once, in place, no widened copy).  GATE: the head of a stream-manager iteration rides along in the same launch: the
+// workgroup that transforms a stream's FIRST frame also takes the vad sum of its new samples (the masks silent / reset) and writes
+// its next sample carry (detector.py:168-183) -- see the block below.
 #ifndef KWS_FE_OCC
 #define KWS_FE_OCC 6          // workgroups per CU the register allocation aims at (tools/build_variant.sh -DKWS_FE_OCC=n for A/B)
 #endif
@@ -110,56 +109,15 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
     const int hi = lane >> 4, lo = lane & 15;          // stage 1: (frame j of 4, n2); stage 2 / MFMA: (g, frame f of 16)
     const unsigned total = (unsigned)p.B * (unsigned)p.T;
     // XCD-aware block -> frame-block map.  Workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own L2;
-    // a stream's frames span two or three 16-frame blocks, every frame re-reads 240 samples of its predecessor, and the
-    // gate blocks read the whole rows of the same streams.  Giving XCD x the CONTIGUOUS run of blocks
-    // [x G/8, (x+1) G/8) keeps all readers of a row behind one L2, so the PCM leaves HBM once (the grid is a multiple of 8).
-    // GATE: besides the transform blocks the grid holds "gate" blocks -- the head of the stream-manager iteration: vad over the new
-    // samples -> silent / reset masks, and the next sample carry (detector.py:168-183).  Workgroups go round-robin over the 8 XCDs
-    // (blockIdx % 8), each with its own L2, and are dispatched in index order.  XCD x transforms the CONTIGUOUS run of frame
-    // blocks [x F, (x+1) F), F = fft_blocks / 8 (a stream's frames span two or three blocks and re-read 240 samples each: one L2
-    // serves them all), and in its sequence every gate block sits IN FRONT OF the p.gate_run transform blocks whose streams
-    // (first frame inside that run) it handles: the gate brings a PCM row into the L2 the transforms then read it from, or
-    // the other way round -- the PCM leaves HBM once (round 3: 1.72x), and the gate runs beside the transforms, not behind
-    // them (round 3: +9 us per launch).  block_abs_sum IS kws_vad's summation (same association, same bits).
+    // a stream's frames span two or three 16-frame blocks, every frame re-reads 240 samples of its predecessor, and with GATE
+    // the block of a stream's first frame reads its whole row.  Giving XCD x the CONTIGUOUS run of blocks [x F, (x+1) F),
+    // F = fft_blocks / 8, keeps all readers of a row behind one L2, so the PCM leaves HBM once (the grid is a multiple of 8).
     constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
     const SampleT* chunk_all = sizeof(SampleT) == 2 ? reinterpret_cast<const SampleT*>(p.pcm_i16) : reinterpret_cast<const SampleT*>(p.pcm);
     const int n_chunk = p.n_samples - p.n_carry;
     const unsigned xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;       // XCD, position in that XCD's sequence
     const unsigned F = (unsigned)p.fft_blocks >> 3;                   // transform blocks per XCD
-    unsigned local = seq;                                               // this XCD's transform block index
-    if constexpr (GATE) {
-        // an XCD's sequence: [gate_batch gate blocks][their gate_batch x gate_run transform blocks], repeated
-        const unsigned GB = (unsigned)p.gate_batch, run = (unsigned)p.gate_run, per = GB * (run + 1u);
-        const unsigned jb = seq / per, rem = seq - jb * per;
-        const unsigned jg = jb * GB + rem;
-        if (rem < GB) {
-            const unsigned T = (unsigned)p.T;
-            const unsigned l_lo = jg * run < F ? jg * run : F, l_hi = l_lo + run < F ? l_lo + run : F;
-            const unsigned f_lo = 16u * (xcd * F + l_lo), f_hi = 16u * (xcd * F + l_hi);
-            unsigned s_lo = (f_lo + T - 1) / T, s_hi = (f_hi + T - 1) / T;
-            s_lo = s_lo < (unsigned)p.B ? s_lo : (unsigned)p.B;
-            s_hi = s_hi < (unsigned)p.B ? s_hi : (unsigned)p.B;
-            for (unsigned b0 = s_lo; b0 < s_hi; b0 += 4) {            // four streams per pass, workgroup-uniform
-                const SampleT* rows[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rows[r] = chunk_all + (size_t)(b0 + r < s_hi ? b0 + r : s_hi - 1) * n_chunk;
-                float sums[4];
-                block_abs_sum_rows<SampleT, 4>(rows, n_chunk, sums);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned bs = b0 + r;
-                    if (bs < s_hi) {
-                        if (tid == 0) vad_masks(sums[r], p.vad_thres, bs, p.restart, p.silent, p.reset);
-                        carry_tail<SampleT>(p.carry + (size_t)bs * p.n_carry, p.n_carry, rows[r], n_chunk, p.next + (size_t)bs * p.n_next, p.n_next, tid, 256);
-                    }
-                }
-                __syncthreads();         // the partial sums in LDS are reused by the next pass
-            }
-            return;
-        }
-        local = jb * GB * run + (rem - GB);
-    }
-    if (local >= F) return;                                            // surplus position of the last batch (uniform)
+    const unsigned local = seq;                                         // this XCD's transform block index
     const unsigned blk = xcd * F + local;
     const unsigned f0 = blk * 16u;
     if (f0 >= total) return;                            // padding block of the rounded-up grid (uniform: before any barrier)
@@ -169,6 +127,51 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
 #define KWS_FE_STAMP(i) do {} while (0)
 #endif
     KWS_FE_STAMP(0);
+
+    // GATE: the stream whose FIRST frame lies in this block gets its vad sum, masks and next carry here.  The row is requested
+    // before the frames' samples and summed while those are in flight; the four wave totals cross at the transform's own first
+    // barrier.  block_abs_sum's association term by term (thread t owns groups t, t + 256, ...; shuffle tree; the four wave
+    // totals pairwise), so kws_vad, the stream manager's gate kernel and this one still take the same decision on the same
+    // samples.  The transform reads the same row right behind: the PCM leaves HBM once (67 MB per 4096 x 3600-sample launch; gate
+    // workgroups in front of the transforms pulled each XCD's 7 MB of rows through its 4 MB L2 first: 94-100 MB; round 3: 140).
+    __shared__ float gate_part[4];
+    unsigned gate_b = 0xffffffffu;                      // workgroup-uniform: the stream handled the fast way
+    float gate_v[4][4];
+    if constexpr (GATE) {
+        const unsigned T = (unsigned)p.T;
+        const unsigned f_end = f0 + 16u < total ? f0 + 16u : total;
+        const unsigned sb0 = (f0 + T - 1u) / T;
+        const bool fast = n_chunk <= 4096 && (n_chunk & 3) == 0 && ((size_t)n_chunk * sizeof(SampleT)) % (4 * sizeof(SampleT)) == 0 &&
+                          (reinterpret_cast<uintptr_t>(chunk_all) & (4 * sizeof(SampleT) - 1)) == 0;
+        for (unsigned sb = sb0; sb < (unsigned)p.B && sb * T < f_end; ++sb) {
+            const SampleT* row = chunk_all + (size_t)sb * n_chunk;
+            if (fast && sb == sb0) {
+                gate_b = sb;
+                const int full = n_chunk >> 2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = tid + 256 * k;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gate_v[k][e] = 0.f;
+                    if (i < full) {
+                        if constexpr (sizeof(SampleT) == 2) {
+                            const short4 q4 = reinterpret_cast<const short4*>(row)[i];
+                            gate_v[k][0] = (float)q4.x * kScale; gate_v[k][1] = (float)q4.y * kScale; gate_v[k][2] = (float)q4.z * kScale; gate_v[k][3] = (float)q4.w * kScale;
+                        } else {
+                            const float4 q4 = reinterpret_cast<const float4*>(row)[i];
+                            gate_v[k][0] = q4.x; gate_v[k][1] = q4.y; gate_v[k][2] = q4.z; gate_v[k][3] = q4.w;
+                        }
+                    }
+                }
+            } else {
+                // a second stream starting in this block (chunks shorter than 16 frames), long or unaligned rows: one after the other
+                const float tot = block_abs_sum<SampleT>(row, n_chunk, nullptr);
+                if (tid == 0) vad_masks(tot, p.vad_thres, sb, p.restart, p.silent, p.reset);
+                carry_tail<SampleT>(p.carry + (size_t)sb * p.n_carry, p.n_carry, row, n_chunk, p.next + (size_t)sb * p.n_next, p.n_next, tid, 256);
+                __syncthreads();
+            }
+        }
+    }
 
     // ---- stage 1: this wave's four frames ----
     {
@@ -216,6 +219,14 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KWS_FE_STAMP(1);
 #endif
+        if (GATE && gate_b != 0xffffffffu) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)      // a thread without group k adds +0: the same bits as not adding
+                acc += (fabsf(gate_v[k][0]) + fabsf(gate_v[k][1])) + (fabsf(gate_v[k][2]) + fabsf(gate_v[k][3]));
+            acc = wave_sum_lane0(acc);
+            if (lane == 0) gate_part[w] = acc;
+        }
         // Z_b[c] = sum_a x[5a + b] W5^{ac}
         float z0[5];
         c32 z1[5], z2[5];
@@ -254,6 +265,11 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
     KWS_FE_STAMP(2);
     __syncthreads();
     KWS_FE_STAMP(3);
+    if (GATE && gate_b != 0xffffffffu) {
+        if (tid == 0) vad_masks((gate_part[0] + gate_part[1]) + (gate_part[2] + gate_part[3]), p.vad_thres, gate_b, p.restart, p.silent, p.reset);
+        carry_tail<SampleT>(p.carry + (size_t)gate_b * p.n_carry, p.n_carry, chunk_all + (size_t)gate_b * n_chunk, n_chunk,
+                            p.next + (size_t)gate_b * p.n_next, p.n_next, tid, 256);
+    }
 
     // ---- stage 2: pass q = w, k1 = 4w + g ----
     const int g = hi, f = lo, q = w;
@@ -391,26 +407,7 @@ hipError_t launch_mel_fft400(const FrontendParams& p, int B, hipStream_t st) {
     FrontendParams q = p;
     q.fft_blocks = (int)grid;
     if (!p.gate) return p.pcm_i16 ? launch_fft400_tiles<int16_t, false>(q, grid, st) : launch_fft400_tiles<float, false>(q, grid, st);
-    // one gate block per gate_run transform blocks of an XCD's sequence: kGateStreams streams' worth of frames.  16 streams
-    // measured best at 4096 x 3600 samples (tools/exp_gate_ab.sh: 1/2/4/8/16/24/32 -> 44.4/43.2/40.7/38.2/36.5/41.7/48.9 us per
-    // fused launch; 32.3 without the gate)
-    static const unsigned kGateStreams = [] { const char* e = getenv("KWS_FE_GATE_STREAMS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 16u; }();
-    const unsigned F = grid / 8;
-    unsigned run = (kGateStreams * (unsigned)p.T + 15u) / 16u;
-    run = run < 1u ? 1u : run;
-    q.gate_run = (int)run;
-    static const unsigned kGateBatch = [] { const char* e = getenv("KWS_FE_GATE_BATCH"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 0u; }();
-    // gate blocks per batch in an XCD's sequence; default: ALL of them first.  Interleaving them with their transform blocks
-    // (batches of 1 / 4 / 16) measured 43.7 / 48.5 / 41.8 us per launch against 36.7 with the gate blocks in front, and only the
-    // finest interleave with 8-stream blocks brought the L2-miss read traffic down to the algorithmic 67 MB (71 MB; in front:
-    // 94 MB -- the gate blocks pull 7 MB of rows per XCD through a 4 MB L2 before the transforms arrive; round 3: 140 MB).
-    q.gate_batch = (int)(kGateBatch ? kGateBatch : (F + run - 1) / run);
-    // per XCD: whole batches of (kGateBatch gate blocks + kGateBatch x run transform blocks); the last batch's surplus positions
-    // find no work and leave at once
-    const unsigned gb = (unsigned)q.gate_batch;
-    const unsigned batches = (F + gb * run - 1) / (gb * run);
-    const unsigned seq_len = batches * gb * (run + 1u);
-    return p.pcm_i16 ? launch_fft400_tiles<int16_t, true>(q, 8u * seq_len, st) : launch_fft400_tiles<float, true>(q, 8u * seq_len, st);
+    return p.pcm_i16 ? launch_fft400_tiles<int16_t, true>(q, grid, st) : launch_fft400_tiles<float, true>(q, grid, st);
 }
 
 }  // namespace kws

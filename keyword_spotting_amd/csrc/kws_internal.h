@@ -174,7 +174,7 @@ struct FrontendParams {
     // fft_frontend.hip only, the head of a stream-manager iteration fused into the same launch (gate != 0): vad over the new
     // samples -> silent / reset masks, and the next sample carry (the last n_next samples of [carry | chunk])
     int gate;
-    int fft_blocks, gate_run, gate_batch; // set by launch_mel_fft400: transform blocks in the grid (multiple of 8); transform blocks per gate block in an XCD's sequence
+    int fft_blocks;      // set by launch_mel_fft400: transform blocks in the grid (multiple of 8)
     float vad_thres;
     const uint8_t* restart;
     uint8_t* silent;

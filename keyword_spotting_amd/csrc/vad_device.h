@@ -52,53 +52,6 @@ __device__ __forceinline__ float block_abs_sum(const SampleT* __restrict__ x, in
 }
 
 
-// NS rows at once, each with block_abs_sum's association (hence its bits): the loads of all rows are in flight together and the
-// rows share the shuffle steps' latency and ONE barrier -- a gate workgroup that walks its streams one block_abs_sum at a time
-// pays the whole load -> add -> shuffle -> LDS -> barrier chain per stream.  totals[] valid in thread 0.
-template <typename SampleT, int NS>
-__device__ __forceinline__ void block_abs_sum_rows(const SampleT* const (&x)[NS], int N, float (&totals)[NS]) {
-    constexpr float kScale = sizeof(SampleT) == 2 ? 1.0f / 32768.0f : 1.0f;
-    float acc[NS];
-    bool vec[NS];
-#pragma unroll
-    for (int r = 0; r < NS; ++r) { acc[r] = 0.f; vec[r] = (reinterpret_cast<uintptr_t>(x[r]) & (4 * sizeof(SampleT) - 1)) == 0; }
-    const int full = N / 4;
-    for (int i = threadIdx.x; i < (N + 3) / 4; i += 256) {
-        float v[NS][4];
-#pragma unroll
-        for (int r = 0; r < NS; ++r) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[r][e] = 0.f;
-            if (i < full && vec[r]) {
-                if constexpr (sizeof(SampleT) == 2) {
-                    const short4 q = reinterpret_cast<const short4*>(x[r])[i];
-                    v[r][0] = (float)q.x * kScale; v[r][1] = (float)q.y * kScale; v[r][2] = (float)q.z * kScale; v[r][3] = (float)q.w * kScale;
-                } else {
-                    const float4 q = reinterpret_cast<const float4*>(x[r])[i];
-                    v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z; v[r][3] = q.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * i + e < N) v[r][e] = (float)x[r][4 * i + e] * kScale;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NS; ++r) acc[r] += (fabsf(v[r][0]) + fabsf(v[r][1])) + (fabsf(v[r][2]) + fabsf(v[r][3]));
-    }
-#pragma unroll
-    for (int r = 0; r < NS; ++r)
-        for (int off = 32; off > 0; off >>= 1) acc[r] += __shfl_down(acc[r], off);
-    __shared__ float part[NS][4];
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int r = 0; r < NS; ++r) part[r][threadIdx.x >> 6] = acc[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < NS; ++r) totals[r] = (part[r][0] + part[r][1]) + (part[r][2] + part[r][3]);      // valid in thread 0
-}
-
 // The same sum, the same association of every addition -- hence the same bits -- by ONE wave: lane l plays threads l, 64 + l,
 // 128 + l, 192 + l of the block above (four partial sums), each "wave" of them is folded by the same shuffle tree, and the
 // four totals meet in the same order.  For kernels that have a wave to spare but no workgroup barrier.  Valid in lane 0.
@@ -137,6 +90,22 @@ __device__ __forceinline__ float wave_abs_sum(const SampleT* __restrict__ x, int
     for (int t = 0; t < 4; ++t)
         for (int off = 32; off > 0; off >>= 1) acc[t] += __shfl_down(acc[t], off);
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+// acc summed over the wave with the association of the `acc += __shfl_down(acc, off)` tree above (off = 32 ... 1) -- valid in lane 0,
+// the same bits -- but without LDS: __shfl_down is a ds_bpermute round trip per step; here the halves meet through gfx950's
+// v_permlane32_swap / v_permlane16_swap and the last four steps through DPP row shifts.  (fp32 addition commutes, so
+// "lane l adds lane l + off" only fixes WHICH pairs meet at each level.)
+__device__ __forceinline__ float wave_sum_lane0(float acc) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+    acc = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);                 // lanes < 32: a[l] + a[l + 32]
+    sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+    acc = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);                 // lanes < 16: x[l] + x[l + 16]
+#define KWS_SHL(ctrl_) acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), ctrl_, 0xf, 0xf, true));
+    KWS_SHL(0x108) KWS_SHL(0x104) KWS_SHL(0x102) KWS_SHL(0x101)           // row_shl 8, 4, 2, 1: lane l + lane l + off
+#undef KWS_SHL
+    return acc;
 }
 
 // the masks one loop iteration of detector.py:158-209 consumes, from the chunk's vad sum: silent (-> the decode window is
