@@ -1,5 +1,5 @@
 // Phase timing of mel_fft400_kernel (s_memtime stamps per wave): where does a wave's lifetime go?
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DKWS_FE_TIMING -I include -I keyword_spotting_amd/csrc tools/ubench/fe_phases.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DKWS_FE_TIMING -I include -I keyword_spotting_amd/csrc tools/ubench/fe_phases.hip
 #define KWS_FE_TIMING 1
 #include "../../keyword_spotting_amd/csrc/fft_frontend.hip"
 #include <algorithm>
