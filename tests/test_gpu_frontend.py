@@ -175,6 +175,21 @@ def test_carry_form_equals_concatenation_and_streams_like_the_host_loop():
         got = mgr.feed_pcm(torch.from_numpy(piece), fe).cpu().numpy()
         np.testing.assert_array_equal(got, want)
         assert torch.equal(mgr.state, det.state)
+    # long chunks: window rows wider than a wave (max_frames 120 -> 128-byte rows), 5 chunks queued: the window walk takes ten
+    # 64-cell trips with rows straddling trips, and every chunk length differs
+    det = HotwordDetector(DeployModel(cfg, w), batch=3, label="1", window_chunks=5)
+    mgr = StreamManager(DeployModel(cfg, w), 3, label="1", window_chunks=5, max_frames=120)
+    pcm = (rng.standard_normal((3, 150000)) * 0.2).astype(np.float32)
+    pos, fired = 0, 0
+    for n in (16000, 19000, 5000, 17777, 3600, 18000, 16001, 12000, 9000, 15000):
+        piece = pcm[:, pos:pos + n]
+        pos += n
+        want = np.zeros(3, np.int32)
+        want[det.feed_pcm(piece, fe)] = 1
+        got = mgr.feed_pcm(torch.from_numpy(piece), fe).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        fired += int(got.sum())
+    assert fired > 0
 
 
 def test_session_run_takes_the_pcm_feed_of_the_shipped_graph():
