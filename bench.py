@@ -277,6 +277,17 @@ def secondary_lines(device):
     return out
 
 
+def visible_gpus():
+    """GPUs a fresh child process sees (torch.cuda.device_count() there), or None when the probe itself fails.  The calling
+    process never touches the GPU runtime: bench.py's launcher only starts children."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception:
+        return None
+
+
 def usable_cores():
     """(threads to use, logical CPUs visible, cgroup quota or None): floor of the cgroup v2/v1 CPU quota when there is
     one, else the size of the affinity mask."""
@@ -440,6 +451,14 @@ def main(argv=None, model_factory=None):
         # not under torchrun: start one rank per GPU as CHILD processes (nothing here has touched the GPU yet)
         import socket
         import subprocess
+        if args.dist_backend == "nccl" and not stub:
+            # one rank per GPU over RCCL: fewer GPUs than ranks is decided HERE, before any rendezvous, by a child probe (the
+            # launcher itself never initialises the GPU runtime: it only ever starts children)
+            n_vis = visible_gpus()
+            if n_vis is not None and n_vis < args.gpus:
+                sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this box (one rank per GPU over RCCL); nothing was run\n"
+                                 % (args.gpus, n_vis))
+                raise SystemExit(2)
         sock = socket.socket()
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -456,6 +475,13 @@ def main(argv=None, model_factory=None):
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
+    if not stub and args.dist_backend == "nccl" and world > 1 and torch.cuda.device_count() < world:
+        # under an external torchrun on a box with fewer GPUs than ranks: say so once and leave before the rendezvous
+        # (device_count() does not initialise the GPU runtime)
+        if rank == 0:
+            sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this box (one rank per GPU over RCCL); nothing was run\n"
+                             % (world, torch.cuda.device_count()))
+        raise SystemExit(2)
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -472,8 +498,6 @@ def main(argv=None, model_factory=None):
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-        if args.dist_backend == "nccl" and world > torch.cuda.device_count():
-            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU over RCCL)" % (world, torch.cuda.device_count()))
         device = torch.device("cuda", local_rank % torch.cuda.device_count())
         torch.cuda.set_device(device)
         from keyword_spotting_amd.rnn_ctc import DeployModel
@@ -510,6 +534,7 @@ def main(argv=None, model_factory=None):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    clock_mhz = sharding.read_sclk_mhz(device)      # sampled while the last steps are still running (sysfs read; None if unreadable)
     device_sync()
     elapsed_own = time.perf_counter() - t0          # this rank alone (per_rank); `value` uses the barrier-to-barrier time
     sharding.barrier(dist, sync_device)
@@ -520,7 +545,10 @@ def main(argv=None, model_factory=None):
     ranks_seen = sharding.count_ranks(dist, sync_device)
     # who took part: host, device identity and own rate of every rank, so that an N-GPU line proves N distinct devices and
     # shows the slowest one (8 bytes of bookkeeping per rank after the timed region; not a data-path collective)
-    per_rank = sharding.gather_rank_info(dist, sharding.rank_identity(rank, local_rank, device, B * T * args.steps / elapsed_own))
+    me = sharding.rank_identity(rank, local_rank, device, B * T * args.steps / elapsed_own)
+    me["kernel_ms"] = [k[0] / max(k[1], 1) for k in ktimes]       # this rank's own per-layer kernel time (HIP events): a slow rank explains itself
+    me["clock_mhz_if_readable"] = clock_mhz
+    per_rank = sharding.gather_rank_info(dist, me)
 
     if rank == 0:
         value = frames / seconds

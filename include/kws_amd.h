@@ -80,8 +80,9 @@ typedef struct kws_model* kws_handle;
 enum { KWS_KERNEL_AUTO = 0, KWS_KERNEL_GENERIC = 1, KWS_KERNEL_RESIDENT = 2 };
 enum { KWS_DECODE = 0, KWS_DECODE2 = 1, KWS_DECODE_STRICT = 2 };
 
-/* "kws_amd <ver> (gfx950; HIP x.y.z; <compiler version>; bf16 mfma-vgpr-form=<0|1>)": the compiler is part of the version
- * because the kernels depend on hand-placed MFMA hazard fences and on an internal LLVM option (csrc/Makefile). */
+/* "kws_amd <ver> (gfx950; HIP x.y.z; <compiler version>; bf16 mfma-vgpr-form=<0|1>; f16x3 mfma-vgpr-form=<0|1>)": the compiler
+ * is part of the version because the kernels depend on hand-placed MFMA hazard fences and, for the two files named, on an
+ * internal LLVM option that csrc/Makefile applies only when this hipcc accepts it. */
 const char* kws_version(void);
 /* sizeof(kws_config) / sizeof(kws_frontend_config) as this library was compiled: a binding written in another
  * language (ctypes, cffi, JNI ...) compares it with its own struct declaration at load time, so a field added here

@@ -224,8 +224,10 @@ __device__ __forceinline__ void epilogue_flush(const GruLayerParams& p, const Ep
     const int prev = f == 0 ? e.carry[blk * 16 + s] : e.words[(f - 1) * 16 + s];
     const int token = (word >= 0 && word != prev) ? word + 1 : 0;   // utils/prediction.py:76-80
     if (f == n - 1) {
-        e.carry[(blk ^ 1) * 16 + s] = word;
-        if (final_flush && b < p.B && p.prev_word) p.prev_word[b] = word;
+        // the ping-pong slot is for the NEXT block of this group only: after the final flush nobody reads it, and a persistent
+        // workgroup's next group initialises carry[0..15] with no barrier in between (it would race with this store)
+        if (!final_flush) e.carry[(blk ^ 1) * 16 + s] = word;
+        else if (b < p.B && p.prev_word) p.prev_word[b] = word;
     }
     if (mine && p.tokens) p.tokens[row] = (int8_t)token;
 }

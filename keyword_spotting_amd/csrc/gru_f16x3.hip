@@ -10,7 +10,9 @@
 // instead of eight v_mfma_f32_16x16x4_f32 of twice the duration (~51 matrix-pipe cycles per 32 k instead of 256):
 //     main += Wh Xh          lo += Wl Xh + Wh Xl          result = main + 2^-11 lo        (fp32 accumulators)
 // fp16 x fp16 products are exact in fp32; the dropped term Wl Xl 2^-22 is below fp32's own rounding of the product.  The
-// 2^11 scale keeps every lo operand in fp16's normal range (no reliance on how the matrix pipe treats subnormals).  bf16
+// 2^11 scale keeps the lo piece of every value with |v| >= 2^-14 in fp16's normal range; below that hi is itself subnormal
+// and lo smaller still, and the path relies on the matrix pipe multiplying fp16 subnormals exactly (it does on gfx950:
+// tests/test_gpu_parity.py feeds mel magnitudes down to 1e-6, whose pieces are all subnormal; kws_selftest runs the same kernels).  bf16
 // splits would need 3 + 3 pieces and six products for the same 24 bits; fp16's 11-bit pieces need two and three.
 // Range: |hidden| <= 1; weights must be < 64 in magnitude (kws_create checks); mel is pre-scaled by 2^-8 (and the
 // x-part weights of the first layer by 2^8, both exact), so |mel| up to 1.6e7 is represented and larger values saturate.
@@ -545,10 +547,12 @@ gru_layer_f16x3(const GruF16Params p) {
             if constexpr (LAST) {
                 // the previous 16 frames' logits leave here, not at the end of frame t-1: between the x stream's tail and its next
                 // start the fewest registers are live, and the flush (softmax, decode rule, stores) needs ~60 of its own
+#ifndef KWS_ABL_NOFLUSH      // experiment builds only (tools/build_variant.sh): what the periodic flush costs
                 if (t > 0 && (t & (kRingFrames - 1)) == 0) {
                     lds_barrier();
                     epilogue_flush(p.epi, epi, group, t - kRingFrames, kRingFrames, w, lane, false);
                 }
+#endif
             }
             KWS_STAMP(9);
             // the next frame's x-part starts beside the r path: its accumulators (bias), first input chunks and operand groups
@@ -666,6 +670,14 @@ gru_layer_f16x3(const GruF16Params p) {
                 *reinterpret_cast<f32x4*>(p.state_out + (size_t)b * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
         }
     }
+}
+
+bool gru_f16x3_vgpr_form() {
+#ifdef KWS_F16X3_VGPR_FORM
+    return true;
+#else
+    return false;
+#endif
 }
 
 bool gru_f16x3_supported(int hidden, int n_mel) { return hidden == 128 && n_mel % 4 == 0 && n_mel >= 4 && n_mel <= 64; }

@@ -119,7 +119,27 @@ struct kws_model {
     std::vector<hipEvent_t> event_pool;
     std::vector<float> ms_sum;
     std::vector<int32_t> launches;
-    std::string launch_name[8];      // kernel(s) the last kws_step launched per profiling slot (kws_last_launch)
+    // kernel the last kws_step launched per profiling slot, as a small tag: the name is only formatted when somebody asks
+    // (kws_last_launch, kws_selftest) -- not on the launch path, where a 22-frame call is ~100 us of device time
+    enum LaunchFamily : uint8_t { kNone = 0, kBf16Stack, kF16x3, kPipelined, kOctbit, kOctbitFc, kResident, kGeneric };
+    struct LaunchTag { uint8_t family = kNone, kx = 0, first = 0, last = 0; };
+    LaunchTag launch_tag[8];
+    std::string launch_name(int slot) const {
+        const LaunchTag& t = launch_tag[slot];
+        char nm[96];
+        nm[0] = 0;
+        switch (t.family) {
+            case kBf16Stack: return kws::gru_stack_bf16_kernel_name(bf_kx0, cfg.num_layers);
+            case kF16x3: snprintf(nm, sizeof(nm), "gru_layer_f16x3<%d, %s, %s>", t.kx, t.first ? "true" : "false", t.last ? "true" : "false"); break;
+            case kPipelined: snprintf(nm, sizeof(nm), "gru_stack_generic_pipelined<%d> (all %d layers, one launch)", t.kx, cfg.num_layers); break;
+            case kOctbit: snprintf(nm, sizeof(nm), "gru_layer_octbit_kernel"); break;
+            case kOctbitFc: snprintf(nm, sizeof(nm), "gru_layer_octbit_kernel + octbit_fc_kernel"); break;
+            case kResident: snprintf(nm, sizeof(nm), "gru_layer_resident<%d, %s, %s>", t.kx, t.first ? "true" : "false", t.last ? "true" : "false"); break;
+            case kGeneric: snprintf(nm, sizeof(nm), "gru_layer_generic<%d, %s, %s>", t.kx, t.first ? "true" : "false", t.last ? "true" : "false"); break;
+            default: break;
+        }
+        return nm;
+    }
 };
 
 struct kws_window {
@@ -271,8 +291,8 @@ extern "C" {
 const char* kws_version(void) {
     static const std::string v = [] {
         char buf[384];
-        snprintf(buf, sizeof(buf), "kws_amd 0.4 (gfx950; HIP %d.%d.%d; %s; bf16 mfma-vgpr-form=%d)", HIP_VERSION_MAJOR, HIP_VERSION_MINOR,
-                 HIP_VERSION_PATCH, __VERSION__, kws::gru_bf16_vgpr_form() ? 1 : 0);
+        snprintf(buf, sizeof(buf), "kws_amd 0.5 (gfx950; HIP %d.%d.%d; %s; bf16 mfma-vgpr-form=%d; f16x3 mfma-vgpr-form=%d)", HIP_VERSION_MAJOR,
+                 HIP_VERSION_MINOR, HIP_VERSION_PATCH, __VERSION__, kws::gru_bf16_vgpr_form() ? 1 : 0, kws::gru_f16x3_vgpr_form() ? 1 : 0);
         return std::string(buf);
     }();
     return v.c_str();
@@ -422,12 +442,30 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
         // holds W[row(c,g,j)][16n+i], j = 0..7, rows in gru_bf16's K permutation.  The first layer's x-part is scaled by 2^8
         // (the kernel feeds mel * 2^-8: both exact) so that mel magnitudes far beyond fp16's 65504 stay representable.
         const float* q = static_cast<const float*>(weights_blob);
-        for (size_t i = 0; i < weights_floats(cfg); ++i)
-            if (!(std::fabs(q[i]) < 64.0f)) {
-                delete m;
-                return fail(KWS_ERR_UNSUPPORTED, "f16x3 path: weight %zu = %g is outside (-64, 64) (fp16 operands; x-part scaled by 256, "
-                            "candidate by 2 log2 e)", i, (double)q[i]);
+        {
+            // only the matrices become fp16 operands (x-part scaled by 256, candidate by 2 log2 e: 256 * 2.886 * 64 < 65504); the
+            // biases and bfc stay fp32 in the kernels and may be of any size
+            const float* base = q;
+            const float* wq_ = q;
+            int in_c = cfg->n_mel;
+            auto range_ok = [&](const float* w, size_t n, const char* what, int layer) -> const float* {
+                for (size_t i = 0; i < n; ++i)
+                    if (!(std::fabs(w[i]) < 64.0f)) {
+                        fail(KWS_ERR_UNSUPPORTED, "f16x3 path: %s weight of layer %d (blob index %zu) = %g is outside (-64, 64) (fp16 operands; "
+                             "x-part scaled by 256, candidate by 2 log2 e)", what, layer, (size_t)(w + i - base), (double)w[i]);
+                        return nullptr;
+                    }
+                return w + n;
+            };
+            for (int l = 0; l < cfg->num_layers && wq_; ++l) {
+                wq_ = range_ok(wq_, (size_t)(in_c + H) * 2 * H, "gate", l);
+                if (wq_) wq_ = range_ok(wq_ + 2 * H, (size_t)(in_c + H) * H, "candidate", l);
+                if (wq_) wq_ += H;
+                in_c = H;
             }
+            if (wq_) wq_ = range_ok(wq_, (size_t)H * C, "projection", cfg->num_layers);
+            if (!wq_) { delete m; return KWS_ERR_UNSUPPORTED; }
+        }
         int in_l = cfg->n_mel;
         m->f16_kx0 = (cfg->n_mel + 31) / 32;
         for (int l = 0; l < cfg->num_layers; ++l) {
@@ -964,8 +1002,8 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         }
         hipError_t e = kws::launch_gru_stack_bf16(bp, h->bf_kx0, L, st);
         if (e != hipSuccess) return hip_fail(e, "launch gru_stack_bf16");
-        h->launch_name[0] = kws::gru_stack_bf16_kernel_name(h->bf_kx0, L);
-        for (int l = 1; l < L; ++l) h->launch_name[l].clear();
+        h->launch_tag[0] = {kws_model::kBf16Stack, 0, 0, 0};
+        for (int l = 1; l < L; ++l) h->launch_tag[l] = {};
         if (h->profiling) {
             KWS_HIP(hipEventRecord(eb, st));
             h->pending.push_back({0, ea, eb});
@@ -1005,9 +1043,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             }
             hipError_t e = kws::launch_gru_layer_f16x3(fp, first, last, st);
             if (e != hipSuccess) return hip_fail(e, "launch gru_layer_f16x3");
-            char nm[96];
-            snprintf(nm, sizeof(nm), "gru_layer_f16x3<%d, %s, %s>", first ? h->f16_kx0 : 4, first ? "true" : "false", last ? "true" : "false");
-            h->launch_name[l] = nm;
+            h->launch_tag[l] = {kws_model::kF16x3, (uint8_t)(first ? h->f16_kx0 : 4), first, last};
             if (h->profiling) {
                 KWS_HIP(hipEventRecord(eb, st));
                 h->pending.push_back({l, ea, eb});
@@ -1105,15 +1141,12 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
                          : kws::launch_gru_layer_generic(p, H, first, last, st);
             if (e != hipSuccess) return hip_fail(e, resident ? "launch gru_layer_resident" : "launch gru_layer_generic");
         }
-        {
-            char nm[96];
-            if (pipelined) snprintf(nm, sizeof(nm), "gru_stack_generic_pipelined<%d> (all %d layers, one launch)", H / 64, L);
-            else if (int8 && h->oct[l].quantised) snprintf(nm, sizeof(nm), "gru_layer_octbit_kernel%s", l == L - 1 ? " + octbit_fc_kernel" : "");
-            else if (resident) snprintf(nm, sizeof(nm), "gru_layer_resident<%d, %s, %s>", p.KCX, first ? "true" : "false", last ? "true" : "false");
-            else snprintf(nm, sizeof(nm), "gru_layer_generic<%d, %s, %s>", H / 64, first ? "true" : "false", last ? "true" : "false");
-            h->launch_name[l] = nm;
-            if (pipelined) for (int k = 0; k < l; ++k) h->launch_name[k].clear();
-        }
+        if (pipelined) {
+            h->launch_tag[l] = {kws_model::kPipelined, (uint8_t)(H / 64), 0, 0};
+            for (int k = 0; k < l; ++k) h->launch_tag[k] = {};
+        } else if (int8 && h->oct[l].quantised) h->launch_tag[l] = {(uint8_t)(l == L - 1 ? kws_model::kOctbitFc : kws_model::kOctbit), 0, 0, 0};
+        else if (resident) h->launch_tag[l] = {kws_model::kResident, (uint8_t)p.KCX, first, last};
+        else h->launch_tag[l] = {kws_model::kGeneric, (uint8_t)(H / 64), first, last};
         if (int8 && l == L - 1) {
             kws::OctbitFcParams fp;
             memset(&fp, 0, sizeof(fp));
@@ -1603,7 +1636,7 @@ int kws_octbit_quantize(const float* W, int K, int N, int8_t* Wq, float* scale, 
 int kws_last_launch(kws_handle h, int slot, char* buf, size_t n) {
     if (!h || !buf || n == 0) return fail(KWS_ERR_INVALID_ARGUMENT, "null handle / buffer");
     if (slot < 0 || slot >= h->cfg.num_layers) return fail(KWS_ERR_INVALID_ARGUMENT, "slot %d out of range [0,%d)", slot, h->cfg.num_layers);
-    snprintf(buf, n, "%s", h->launch_name[slot].c_str());
+    snprintf(buf, n, "%s", h->launch_name(slot).c_str());
     return KWS_OK;
 }
 
@@ -1701,7 +1734,7 @@ int selftest_case(const kws_config& cfg, int kernel_kind, const std::vector<floa
     if (rc == KWS_OK && kernels) {
         kernels->clear();
         for (int l = 0; l < L; ++l)
-            if (!m->launch_name[l].empty()) *kernels += (kernels->empty() ? "" : " + ") + m->launch_name[l];
+            if (m->launch_tag[l].family != kws_model::kNone) *kernels += (kernels->empty() ? "" : " + ") + m->launch_name(l);
     }
     const std::string keep = g_last_error;
     kws_destroy(m);

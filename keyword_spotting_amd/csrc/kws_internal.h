@@ -115,6 +115,7 @@ struct GruF16Params {
 };
 bool gru_f16x3_supported(int hidden, int n_mel);
 hipError_t launch_gru_layer_f16x3(const GruF16Params& p, bool first, bool last, hipStream_t st);
+bool gru_f16x3_vgpr_form();                                 // gru_f16x3.hip built with -mllvm -amdgpu-mfma-vgpr-form=1 (csrc/Makefile)
 
 // int8 ("octbit") GRU layers and class projection (gru_octbit.hip)
 struct GruOctbitParams {

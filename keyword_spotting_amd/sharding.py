@@ -72,6 +72,33 @@ def rank_identity(rank, local_rank, device, frames_per_s):
     return info
 
 
+def read_sclk_mhz(device):
+    """Current shader clock of `device` in MHz from sysfs (the starred line of pp_dpm_sclk of the DRM card with the device's
+    PCI address), or None: not a GPU, not readable as this user, or no such file.  Informational only (bench.py per_rank)."""
+    if getattr(device, "type", "cpu") != "cuda":
+        return None
+    try:
+        import glob
+        import re
+        import torch
+        props = torch.cuda.get_device_properties(device)
+        want = "%04x:%02x:%02x." % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                slot = re.search(r"PCI_SLOT_NAME=(\S+)", open(os.path.join(card, "uevent")).read())
+                if not slot or not slot.group(1).lower().startswith(want):
+                    continue
+                for ln in open(os.path.join(card, "pp_dpm_sclk")):
+                    m = re.match(r"\s*\d+:\s*(\d+)\s*[Mm][Hh]z\s*\*", ln)
+                    if m:
+                        return int(m.group(1))
+            except Exception:
+                continue
+    except Exception:
+        pass
+    return None
+
+
 def gather_rank_info(dist, info):
     """[info of rank 0, ..., info of rank world-1] on every rank (all_gather_object after the timed region)."""
     if dist is None or not dist.is_initialized():

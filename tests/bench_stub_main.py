@@ -31,7 +31,8 @@ class StubModel(object):
 
     def forward(self, mel, state, prev_word=None, state_out=None, out=None):
         assert tuple(mel.shape[:2]) == self.reserved
-        time.sleep(0.01 * (1 + self.rank))
+        slow = os.environ.get("KWS_STUB_SLOW_RANK")          # default: rank r sleeps (1 + r) x 10 ms; with the variable, only that rank is slow
+        time.sleep(0.01 * (1 + self.rank) if slow is None else (0.04 if self.rank == int(slow) else 0.01))
         self.calls += 1
         if self.profiling:
             self.timed += 1
@@ -40,7 +41,8 @@ class StubModel(object):
         self.profiling = bool(on)
 
     def kernel_times(self, reset=True):
-        r = [(4.0 * self.timed, self.timed), (6.0 * self.timed, self.timed)]
+        k = 1.0 + self.rank if os.environ.get("KWS_STUB_SLOW_RANK") is None else (4.0 if self.rank == int(os.environ["KWS_STUB_SLOW_RANK"]) else 1.0)
+        r = [(4.0 * k * self.timed, self.timed), (6.0 * k * self.timed, self.timed)]
         if reset:
             self.timed = 0
         return r

@@ -109,3 +109,40 @@ def test_bench_main_under_an_external_torchrun_and_single_rank():
     assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and len(one["per_rank"]) == 1
     assert len(line["per_rank"]) == 2 and line["distinct_devices"] == 2
     assert abs(one["value"] - 32 * 8 * 3 / (one["ms_per_step"] * 3e-3)) < 1e-6 * one["value"]
+
+
+def test_bench_main_eight_stub_ranks():
+    """configs[3]'s launch shape (8 ranks on one node) through bench.py's own launcher, model stubbed: eight ranks counted,
+    eight distinct (host, device) pairs, value = 8 x the slowest rank's own rate (weak scaling, MAX-over-ranks time), and
+    every rank reports its per-layer kernel time and a clock field."""
+    stub = os.path.join("tests", "bench_stub_main.py")
+    line = _run_stub_bench([stub, "--gpus", "8", "--steps", "4", "--warmup", "1", "--batch", "16", "--frames", "5",
+                            "--dist-backend", "gloo"], {"KWS_STUB_SLOW_RANK": "5"})
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["distinct_devices"] == 8
+    assert [r["rank"] for r in line["per_rank"]] == list(range(8))
+    assert line["config"]["parallelism"] == "utterance-dp8" and line["scaling"] == "weak"
+    slowest = min(line["per_rank"], key=lambda r: r["mel_frames_per_s"])
+    assert slowest["rank"] == 5
+    assert abs(8 * slowest["mel_frames_per_s"] - line["value"]) < 0.25 * line["value"]
+    assert abs(line["value"] - 8 * 16 * 5 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+    for r in line["per_rank"]:
+        assert len(r["kernel_ms"]) == 2 and "clock_mhz_if_readable" in r
+    assert slowest["kernel_ms"][0] > line["per_rank"][0]["kernel_ms"][0]       # the slow rank explains itself
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_any_rendezvous():
+    """--gpus N on a box with fewer than N GPUs (here: none): ONE clear line, non-zero exit, decided by a child probe before
+    the launcher starts any rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("this box has 8 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    msgs = [ln for ln in r.stderr.splitlines() if "bench.py --gpus 8" in ln]
+    assert len(msgs) == 1 and "GPU(s) visible" in msgs[0] and "nothing was run" in msgs[0]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -302,7 +302,14 @@ def test_f16x3_preconditions_and_its_distance_from_the_fp32_kernels():
     big["layers"][1]["Wc"] = big["layers"][1]["Wc"].copy()
     big["layers"][1]["Wc"][3, 5] = 200.0
     with pytest.raises(_lib.UnsupportedError):
-        _model(SHAPES["A"], big, "f16x3")                         # |w| >= 128 is outside the fp16 pieces' range
+        _model(SHAPES["A"], big, "f16x3")                         # |w| >= 64 is outside the fp16 pieces' range (kws_amd.h)
+    ok = {k: v for k, v in w.items()}
+    ok["layers"] = [dict(lay) for lay in w["layers"]]
+    ok["layers"][0]["bg"] = ok["layers"][0]["bg"].copy()
+    ok["layers"][0]["bg"][7] = 100.0                              # biases (and bfc) stay fp32 in the kernels: any magnitude is fine
+    ok["bfc"] = ok["bfc"].copy()
+    ok["bfc"][2] = -300.0
+    _model(SHAPES["A"], ok, "f16x3")
     with pytest.raises(_lib.UnsupportedError):
         _model(SHAPES["C"], G.init_weights(60, 256, 4, 6), "f16x3")   # hidden 256
     mel = torch.from_numpy(G.synthetic_mel(64, 300, 40, seed=83))
