@@ -99,6 +99,26 @@ def pmc_bytes(pattern, tag):
     return None, os.path.relpath(latest, ROOT)
 
 
+def pmc_field(pattern, tag, field):
+    """One derived figure of a kernel from the latest committed profiles/r<round>_<tag>_pmc.json (None when stale or absent)."""
+    import glob
+    import re
+    rx = re.compile(r"^r(\d+)_%s_pmc\.json$" % re.escape(tag))
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")) if rx.match(os.path.basename(f))]
+    if not files:
+        return None
+    latest = max(files, key=lambda f: int(rx.match(os.path.basename(f)).group(1)))
+    if not profile_is_current(latest):
+        return None
+    for k, c in json.load(open(latest)).items():
+        if pattern in k:
+            if field in c:
+                return c[field]
+            if field == "valu_busy_frac_of_simd_cycles" and c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c:
+                return 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+    return None
+
+
 def secondary_lines(device):
     """Informational figures for the other BASELINE configs, measured after the timed region on rank 0 (never part of
     `value`): the bf16 and int8 variants of the headline workload, the end-to-end PCM -> trigger streaming loop (fp32 and
@@ -183,6 +203,65 @@ def secondary_lines(device):
         out[("configs[1] at fp32 tolerance on the fp16 matrix pipe (%s), %d streams x %d frames" if prec == "f16x3" else
              "configs[2] %s, %d streams x %d frames") % (prec, B, T)] = entry
         m.close()
+    # SURVEY 8(d) config 2, second clause: the streaming hop itself -- T = 22 frames per call (detector.py:119 feeds 3600-sample
+    # chunks), 64 consecutive kws_step calls with the state carried on the device, mel already resident; per-layer kernel time
+    # by HIP events, each layer against the peak of the pipe it runs on, next to the T = 300 figures above.  The T = 1 run
+    # gives the per-launch fixed cost (dispatch, weight staging, un-woven first frame, drain): what a 22-frame call cannot amortise
+    hop_T, hop_calls = 22, 64
+    hop_mel = [(torch.randn(B, hop_T, 40, device=device).abs() * 2).contiguous() for _ in range(4)]
+    for prec in ("fp32", "f16x3", "bf16"):
+        cfg = get_config(precision=prec)
+        m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+        st, pw = m.zero_state(B), m.fresh_prev_word(B)
+        hop_out = {"logits": torch.empty(B, hop_T, cfg.num_classes, device=device), "softmax": torch.empty(B, hop_T, cfg.num_classes, device=device),
+                   "tokens": torch.empty(B, hop_T, dtype=torch.int8, device=device)}
+        m.reserve(B, hop_T)
+        hk = [0]
+        def hop():
+            m.forward(hop_mel[hk[0] % 4], st, prev_word=pw, state_out=st, out=hop_out)
+            hk[0] += 1
+        for _ in range(8):
+            hop()
+        torch.cuda.synchronize(device)
+        m.set_profiling(True)
+        m.kernel_times()
+        t0 = time.perf_counter()
+        for _ in range(hop_calls):
+            hop()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / hop_calls
+        kt = m.kernel_times()
+        names = m.kernel_names()
+        # T = 1: the same handle, 64 calls of one frame
+        one = hop_mel[0][:, :1].contiguous()
+        one_out = {k_: v_[:, :1].contiguous() for k_, v_ in hop_out.items()}
+        for _ in range(4):
+            m.forward(one, st, prev_word=pw, state_out=st, out=one_out)
+        m.kernel_times()
+        for _ in range(hop_calls):
+            m.forward(one, st, prev_word=pw, state_out=st, out=one_out)
+        k1 = m.kernel_times()
+        m.set_profiling(False)
+        nslots = 1 if prec == "bf16" else len(kt)
+        per = [kt[l][0] / max(kt[l][1], 1) for l in range(nslots)]
+        per1 = [k1[l][0] / max(k1[l][1], 1) for l in range(nslots)]
+        peak = PEAK_FP32_TFLOPS if prec == "fp32" else 2500.0
+        mult = 3 if prec == "f16x3" else 1
+        fl = [FLOP_PER_FRAME["total"]] if prec == "bf16" else FLOP_PER_FRAME["layer"]
+        layers_ = []
+        for l in range(nslots):
+            tf = mult * fl[l] * B * hop_T / (per[l] * 1e-3) / 1e12
+            layers_.append({"kernel": names[l], "kernel_ms": per[l], "tflops" + ("_issued" if mult == 3 else ""): tf, "frac": tf / peak,
+                            "kernel_ms_at_T1": per1[l],
+                            "fixed_cost_share_of_the_call": per1[l] / per[l] if per[l] > 0 else None})
+        out["configs[1] T=%d, %d consecutive kws_step calls, state carried, %s, %d streams" % (hop_T, hop_calls, prec, B)] = {
+            "mel_frames_per_s": B * hop_T / dt, "realtime_streams_gru_only": B * hop_T / dt / 100.0, "ms_per_call": dt * 1e3,
+            "kernel_ms_sum": sum(per), "host_and_launch_gap_ms": dt * 1e3 - sum(per),
+            "peak_tflops": peak, "layers": layers_,
+            "what": "mel-fed kws_step only (no front-end, no window): SURVEY 8(d) config 2's streaming-hop entry; `frac` per layer is against the "
+                    "fp32 MFMA peak (fp32), the dense fp16 peak on 3x the flops (f16x3), the dense bf16 peak (bf16)"}
+        m.close()
+    del hop_mel
     # the loop the reference ships: PCM chunks of 225 ms in, trigger decisions out (kws_stream_feed)
     pcm = [(torch.randn(B, 3600, device=device) * 0.1).contiguous() for _ in range(4)]
     fe_ms = None
@@ -242,11 +321,18 @@ def secondary_lines(device):
             alg = B * (3840 * 4 + 22 * cfg.n_mel * 4)
             traffic, src = pmc_bytes("mel_fft400_kernel", "fe")
             rp_ms, rp_src = rocprof_kernel_avg_ms("mel_fft400_kernel", "fe")
+            # The kernel moves exactly its algorithmic bytes (traffic / algorithmic ~ 1.0) at about a third of the HBM peak, so HBM
+            # is not what binds it: it is bound by VALU ISSUE (the 16x25 butterflies; ~580 VALU instructions per wave).  `frac`
+            # is therefore the share of all SIMD-cycles of the launch with the VALU busy (PMC: SQ_ACTIVE_INST_VALU against
+            # GRBM_GUI_ACTIVE, profiles/r*_fe_pmc.json); the HBM fraction is kept beside it as the secondary lens.
+            valu_busy = pmc_field("mel_fft400_kernel", "fe", "valu_busy_frac_of_simd_cycles")
             entry["frontend"] = {"kernel": "mel_fft400_kernel (16x25 real FFT + mel MFMA) + carry_tail", "kernel_ms": fe_ms,
                                  "mel_frames_per_s": B * 22 / (fe_ms * 1e-3),
-                                 "roofline": {"bound": "hbm", "achieved": alg / (fe_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                              "frac": alg / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg,
-                                              "traffic": traffic, "traffic_source": src,
+                                 "roofline": {"bound": "valu-issue", "frac": valu_busy, "unit": "share of SIMD-cycles with the VALU busy (PMC)",
+                                              "achieved": valu_busy, "peak": 1.0,
+                                              "hbm": {"achieved": alg / (fe_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                      "frac": alg / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg,
+                                                      "traffic": traffic, "traffic_source": src},
                                               "kernel_ms_rocprof": rp_ms, "rocprof_source": rp_src}}
         elif prec == "f16x3":
             per = [k_[0] / max(k_[1], 1) for k_ in kt]

@@ -28,9 +28,14 @@
  *     waits for the device once; kws_scratch_stats counts those events).
  *   - return value: KWS_OK or a negative kws_status.  No exceptions, no abort.  The message for the
  *     last failure on the calling thread is kws_last_error().
- *   - a handle is immutable after kws_create except for its scratch buffer and profiling slots:
- *     concurrent kws_step calls on ONE handle must be serialised by the caller (or use one handle
- *     per host thread); different handles are independent.
+ *   - a handle is immutable after kws_create except for its scratch buffer and profiling slots: ONE host thread at a
+ *     time per handle.  The reference's OctbitMatMulOp::Compute is re-entrant (octbit/octbit_mat_mul_op.cc:49) because it
+ *     allocates its temporaries per call; here the inter-layer seams belong to the handle, so the unit of concurrency is the
+ *     handle (0.64 MB of weights + scratch each): one per host thread, each on its own HIP stream -- different handles are
+ *     fully independent (tests/test_gpu_soak.py drives two threads on two handles).  Sharing one handle is detected, not
+ *     undefined: a thread that enters kws_step / kws_reserve / kws_kernel_times while another is inside gets KWS_ERR_BUSY
+ *     and nothing is launched; calls that are serialised by the caller but arrive on a different stream than the call before
+ *     first wait for the device (the previous call's kernels still own the seams), so they are correct, only slower.
  */
 #ifndef KWS_AMD_H_
 #define KWS_AMD_H_
@@ -48,7 +53,8 @@ typedef enum kws_status {
     KWS_ERR_UNSUPPORTED = -2,      /* shape outside what the kernels are built for                    */
     KWS_ERR_HIP = -3,              /* a HIP runtime call failed (message has hipGetErrorString)       */
     KWS_ERR_NO_DEVICE = -4,        /* no gfx950 device visible                                        */
-    KWS_ERR_OUT_OF_MEMORY = -5
+    KWS_ERR_OUT_OF_MEMORY = -5,
+    KWS_ERR_BUSY = -6              /* another host thread is inside kws_step / kws_reserve / kws_kernel_times on this handle */
 } kws_status;
 
 /* Model shape: config/rnn_config.py:57-99 (n_mel :63, hidden_size :84, num_layers :76,

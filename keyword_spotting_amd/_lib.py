@@ -11,6 +11,7 @@ KWS_ERR_UNSUPPORTED = -2
 KWS_ERR_HIP = -3
 KWS_ERR_NO_DEVICE = -4
 KWS_ERR_OUT_OF_MEMORY = -5
+KWS_ERR_BUSY = -6
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_RESIDENT = 0, 1, 2
 DECODE, DECODE2, DECODE_STRICT = 0, 1, 2
 FP32, BF16, INT8, F16X3 = 0, 1, 2, 3
@@ -41,6 +42,10 @@ class InvalidArgumentError(KwsError, ValueError):
 
 class UnsupportedError(KwsError, NotImplementedError):
     pass
+
+
+class BusyError(KwsError):
+    """Another host thread is inside a call on the same handle (one thread at a time per handle)."""
 
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
@@ -116,6 +121,8 @@ def check(rc):
         raise InvalidArgumentError(rc, msg)
     if rc == KWS_ERR_UNSUPPORTED:
         raise UnsupportedError(rc, msg)
+    if rc == KWS_ERR_BUSY:
+        raise BusyError(rc, msg)
     raise KwsError(rc, msg)
 
 

@@ -72,6 +72,9 @@ __device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
     f32x2 r;
     r.x = __builtin_amdgcn_rcpf(d.x);
     r.y = __builtin_amdgcn_rcpf(d.y);
+#ifdef KWS_FAULT_INJECT      // never defined in a product build: tests/test_abi.py builds a deliberately wrong library with it
+    r = r * 1.0078125f;      // (tools/build_variant.sh faulty -DKWS_FAULT_INJECT=1) and expects kws_selftest to reject it
+#endif
     return r;
 }
 __device__ __forceinline__ f32x2 tanh2(f32x2 x) {

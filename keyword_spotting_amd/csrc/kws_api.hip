@@ -1,5 +1,6 @@
 // C ABI of libkws_amd.so (include/kws_amd.h): handle management, weight re-tiling, kws_step.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -52,6 +53,15 @@ int hip_fail(hipError_t e, const char* what) {
     return fail(e == hipErrorOutOfMemory ? KWS_ERR_OUT_OF_MEMORY : KWS_ERR_HIP, "%s: %s", what,
                 hipGetErrorString(e));
 }
+// scope guard of kws_model::in_call
+struct BusyGuard {
+    std::atomic<int>* flag;
+    bool owned;
+    explicit BusyGuard(std::atomic<int>& f) : flag(&f), owned(f.exchange(1, std::memory_order_acquire) == 0) {}
+    ~BusyGuard() { if (owned) flag->store(0, std::memory_order_release); }
+    BusyGuard(const BusyGuard&) = delete;
+    BusyGuard& operator=(const BusyGuard&) = delete;
+};
 #define KWS_HIP(call)                                         \
     do {                                                      \
         hipError_t e_ = (call);                               \
@@ -112,6 +122,13 @@ struct kws_model {
     size_t pipe_groups = 0;
     int* pipe_error_host = nullptr;  // mapped pinned flag the kernel raises if a wait times out
     int* pipe_error_dev = nullptr;
+    // One host thread at a time per handle (kws_amd.h): a second thread that enters kws_step / kws_reserve / kws_kernel_times
+    // while another is inside gets KWS_ERR_BUSY instead of racing on the scratch arena and the profiling slots.
+    std::atomic<int> in_call{0};
+    // The seams are shared by all calls of the handle: a call that arrives on another HIP stream than the one before waits
+    // for the device first (stream switches are rare; the common path pays nothing).
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
     // profiling
     bool profiling = false;
     struct Pending { int slot; hipEvent_t a, b; };
@@ -792,6 +809,8 @@ static int ensure_scratch(kws_handle h, int B, int T) {
 
 int kws_reserve(kws_handle h, int B, int T) {
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    BusyGuard busy(h->in_call);
+    if (!busy.owned) return fail(KWS_ERR_BUSY, "kws_reserve: another host thread is inside a call on this handle");
     if (B < 0 || T < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative B=%d or T=%d", B, T);
     // whichever launch layout kws_step picks for (B, T) -- it depends on kws_set_profiling too -- fits afterwards
     int rc = ensure_scratch(h, B, T);
@@ -833,6 +852,8 @@ int kws_set_profiling(kws_handle h, int enable) {
 
 int kws_kernel_times(kws_handle h, float* ms_sum, int32_t* launches, int reset) {
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    BusyGuard busy(h->in_call);
+    if (!busy.owned) return fail(KWS_ERR_BUSY, "kws_kernel_times: another host thread is inside a call on this handle");
     for (auto& pd : h->pending) {
         KWS_HIP(hipEventSynchronize(pd.b));
         float ms = 0.f;
@@ -940,6 +961,13 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
     hipStream_t st = static_cast<hipStream_t>(stream);
     const kws_config& c = h->cfg;
     const int H = c.hidden, L = c.num_layers;
+    BusyGuard busy(h->in_call);
+    if (!busy.owned)
+        return fail(KWS_ERR_BUSY, "kws_step: another host thread is inside a call on this handle (one thread at a time per handle; "
+                    "use one handle per thread)");
+    if (h->last_stream_valid && st != h->last_stream) KWS_HIP(hipDeviceSynchronize());     // the previous call's kernels still own the seams
+    h->last_stream = st;
+    h->last_stream_valid = true;
     {
         const int rc = check_pipe_error(h);      // raised by an earlier layer-pipelined step of this handle
         if (rc != KWS_OK) return rc;

@@ -194,3 +194,110 @@ def test_layers_overlapped_on_streams_equal_sequential_launches():
             assert torch.equal(b[key], a[key][:k]), (layers, key)
         assert torch.equal(b["state"], a["state"][:, :k]) and torch.equal(pw_b, pw_a[:k])
         assert int((b["tokens"] > 0).sum()) > 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16"])
+def test_two_host_threads_two_handles(precision):
+    """The unit of host concurrency is the handle (kws_amd.h; the reference's Compute is re-entrant,
+    octbit/octbit_mat_mul_op.cc:49): two Python threads, each with its own DeployModel and its own HIP stream, step 200
+    times side by side (ctypes releases the GIL around kws_step; a barrier per step makes the calls collide) and get the
+    bits of running alone on one thread."""
+    import threading
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg = get_config(precision=precision)
+    shapes = ((48, 22, 601), (130, 23, 602))                  # (streams, frames, seed): different batch shapes per thread
+    ws = [G.random_weights(40, 128, 2, 6, seed=s) for _, _, s in shapes]
+    mels = [torch.from_numpy(G.synthetic_mel(b, 3 * t, 40, seed=s + 10)).cuda() for b, t, s in shapes]
+    steps = 200
+
+    def drive(i, stream, gate, out, errors):
+        try:
+            b, t, _ = shapes[i]
+            m = DeployModel(cfg, ws[i])
+            st, pw = m.zero_state(b), m.fresh_prev_word(b)
+            acc_l = torch.zeros(b, t, 6, device="cuda")
+            acc_t = torch.zeros(b, t, dtype=torch.int32, device="cuda")
+            with torch.cuda.stream(stream):
+                for k in range(steps):
+                    if gate is not None:
+                        gate.wait()
+                    mel = mels[i][:, (k % 3) * t:(k % 3 + 1) * t].contiguous()
+                    r = m.forward(mel, st, prev_word=pw, state_out=st)
+                    acc_l += r["logits"]
+                    acc_t += r["tokens"].to(torch.int32)
+                stream.synchronize()
+            out[i] = (acc_l.cpu(), acc_t.cpu(), st.cpu(), pw.cpu())
+            m.close()
+        except Exception as exc:          # surfaced by the main thread
+            errors.append((i, repr(exc)))
+            if gate is not None:
+                gate.abort()
+
+    alone, errors = {}, []
+    for i in range(2):
+        drive(i, torch.cuda.Stream(), None, alone, errors)
+    assert not errors, errors
+    both, gate = {}, threading.Barrier(2)
+    threads = [threading.Thread(target=drive, args=(i, torch.cuda.Stream(), gate, both, errors)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors and len(both) == 2, errors
+    for i in range(2):
+        for x, y in zip(alone[i], both[i]):
+            assert torch.equal(x, y), (precision, i)
+
+
+def test_sharing_one_handle_between_threads_is_detected_not_undefined():
+    """One handle, two host threads, no lock (unsupported: kws_amd.h): every call either completes with the right bits or
+    returns KWS_ERR_BUSY having launched nothing -- never a silently corrupted result.  With the caller's own lock around
+    the calls (the supported way to share) all of them succeed, also when the two threads come in on different streams."""
+    import threading
+    from keyword_spotting_amd import _lib, get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg = get_config()
+    w = G.random_weights(40, 128, 2, 6, seed=611)
+    b, t = 64, 22
+    mel = torch.from_numpy(G.synthetic_mel(b, t, 40, seed=612)).cuda()
+    m = DeployModel(cfg, w)
+    st0 = m.zero_state(b)
+    want = m.forward(mel, st0)
+    torch.cuda.synchronize()
+    want_l, want_s = want["logits"].clone(), want["state"].clone()
+
+    def hammer(lock, stats, bad):
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            for _ in range(300):
+                try:
+                    if lock is not None:
+                        with lock:
+                            r = m.forward(mel, st0)
+                            stream.synchronize()            # the caller's lock covers the call AND its kernels
+                    else:
+                        r = m.forward(mel, st0)
+                        stream.synchronize()
+                except _lib.BusyError:
+                    stats["busy"] += 1
+                    continue
+                stats["ok"] += 1
+                if not (torch.equal(r["logits"], want_l) and torch.equal(r["state"], want_s)):
+                    bad.append(1)
+
+    for lock in (None, threading.Lock()):
+        stats, bad = {"ok": 0, "busy": 0}, []
+        threads = [threading.Thread(target=hammer, args=(lock, stats, bad)) for _ in range(2)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(300)
+        assert stats["ok"] + stats["busy"] == 600 and stats["ok"] >= 300
+        if lock is not None:
+            assert stats["busy"] == 0 and not bad
+        else:
+            # unlocked: a call that was let in ran alone on the host, but its kernels may still overlap the other thread's
+            # next call on the other stream -- kws_step waits for the device when the stream changes, so results stay right
+            assert not bad, "%d corrupted results out of %d" % (len(bad), stats["ok"])
+    m.close()

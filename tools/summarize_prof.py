@@ -46,6 +46,14 @@ for k, c in pmc_json.items():
         # (one wave per SIMD in the resident kernels): the matrix pipe's share of the waves' lifetime
         c["mfma_busy_frac_of_wave_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_WAVE_CYCLES"])
         c["wave_parked_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+    if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+        # SQ_ACTIVE_INST_VALU: quad-cycles in which a SIMD's VALU was executing, summed over the 1024 SIMDs; GRBM_GUI_ACTIVE:
+        # busy cycles summed over the 8 XCDs -> the share of all SIMD-cycles of the launch with the VALU busy (the binding
+        # number of an issue-bound kernel such as the FFT front-end; the same ratio for the matrix pipe beside it)
+        simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
+        c["valu_busy_frac_of_simd_cycles"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            c["mfma_busy_frac_of_simd_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         c["hbm_read_bytes_corrected"] = c["FETCH_SIZE"] * 1024 * 2
         c["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
