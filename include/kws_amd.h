@@ -223,6 +223,20 @@ int kws_window_destroy(kws_window_handle h);
 int kws_window_step(kws_window_handle h, const float* softmax /*[B,T,C]*/, int T, const uint8_t* clear_before,
                     const char* label, int32_t* hit /*[B]*/, uint8_t* restart /*[B] or NULL*/, void* stream);
 
+/* The same window step in incremental form: the window keeps a SUMMARY per queued chunk (first / last frame word and where the
+ * label matcher ends up for each of its <= 16 entry states) instead of the chunk's frames, and evaluates the <= max_chunks
+ * summaries, oldest first -- O(chunks) per step, not O(frames in the window).  Whether a chunk's first frame emits depends
+ * on the chunk before it in the window, which is what an eviction changes: that one decision is taken at evaluation time, so
+ * the result is exactly the re-scan's (property-tested against it, evictions / empty chunks / clears / triggers included:
+ * tests/test_window_incremental.py, tests/test_gpu_window.py).  Same arguments and results as kws_window_step.  The summaries
+ * are label-specific: the first call binds `label` to the window (uploads its matcher: synchronises once), later calls must
+ * pass the same one (KWS_ERR_INVALID_ARGUMENT otherwise).  The incremental state is separate from kws_window_step's frame
+ * ring: drive a window through ONE of the two entry points.  kws_stream_feed uses this form -- inside the last GRU layer's
+ * launch where that kernel has the tail (fp32 / f16x3 / bf16 stacks at hidden = 128, chunks of <= 64 frames, windows of
+ * <= 32 chunks), as a launch of its own otherwise. */
+int kws_window_step_incremental(kws_window_handle h, const float* softmax /*[B,T,C]*/, int T, const uint8_t* clear_before,
+                                const char* label, int32_t* hit /*[B]*/, uint8_t* restart /*[B] or NULL*/, void* stream);
+
 /* The whole loop iteration of detector.py:158-209 for B streams as ONE call (device-side stream manager, native):
  *   data = ring_buffer.get()                      `pcm` [B,n]: float samples, or int16 PCM scaled by 2^-15 (:40-43,74-79)
  *   vad(data, vad_thres) false -> clean_state() + prob_queue.clear()                                   (:168-177)
@@ -230,8 +244,9 @@ int kws_window_step(kws_window_handle h, const float* softmax /*[B,T,C]*/, int T
  *   softmax, state = sess.run(...)                 front-end + GRU stack on the carried state           (:190-196)
  *   prob_queue.add(softmax); ctc_decode2 over the window; ctc_predict(label)                            (:195-201)
  *   on a hit: window cleared, state reset requested for the next chunk                                  (:202-208)
- * i.e. kws_vad -> kws_frontend_run_carry -> kws_step -> kws_window_step with the mask logic between them fused into
- * the first kernel and no host work per stream.  The handle BORROWS the model, front-end and window handles (they
+ * i.e. kws_vad -> kws_frontend_run_carry -> kws_step -> kws_window_step_incremental with the mask logic fused into the first
+ * kernel, the window step into the last, and no host work per stream: three launches per chunk (gate + front-end, two GRU
+ * layers), two for the bf16 stack.  `label` is bound to `window` at kws_stream_create.  The handle BORROWS the model, front-end and window handles (they
  * should outlive it; a feed after one of them was destroyed fails with KWS_ERR_INVALID_ARGUMENT) and the caller-owned
  * device buffers `state` [L,B,H] (zero it to start) and `restart` [B] u8 (zero it); it owns the sample carry, the
  * mel / softmax staging and the masks.  An empty chunk (n == 0) is skipped as detector.py:164-166 does.  Fewer than

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "kws_window_create": (_i, [_i, _i, _i, _i, _f, ctypes.POINTER(_vp)]),
     "kws_window_destroy": (_i, [_vp]),
     "kws_window_step": (_i, [_vp, _vp, _i, _vp, ctypes.c_char_p, _vp, _vp, _vp]),
+    "kws_window_step_incremental": (_i, [_vp, _vp, _i, _vp, ctypes.c_char_p, _vp, _vp, _vp]),
     "kws_stream_create": (_i, [_vp, _vp, _vp, _i, _i, _f, ctypes.c_char_p, _vp, _vp, ctypes.POINTER(_vp)]),
     "kws_stream_destroy": (_i, [_vp]),
     "kws_stream_reset": (_i, [_vp]),

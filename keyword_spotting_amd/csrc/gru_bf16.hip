@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "gru_device.h"
+#include "window_device.h"
 
 namespace kws {
 
@@ -444,7 +445,8 @@ gru_stack_bf16(const GruBf16Params p) {
 // from a second wave -- waves_per_simd.hip: their MFMAs and VALU share one pipe.)  256 registers per wave: layer 0 keeps
 // its 36 operands in registers, layer 1 its 32 gate operands; layer 1's 16 candidate operands stream from LDS (64 KiB).
 // ------------------------------------------------------------------------------------------------------------
-template <int KX0>
+// WINDOW: the decode-window step of the stream manager rides at the end of every group (window_device.h)
+template <int KX0, bool WINDOW = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gru_stack_bf16_ls(const GruBf16Params p) {
     constexpr int H = 128, NL = 2;
@@ -465,7 +467,8 @@ gru_stack_bf16_ls(const GruBf16Params p) {
     u32x4* xsb = rhb + NL * 4 * 64;                          // [KX0][64]           mel frame (bf16), zero padded
     u32x4* wc1 = xsb + KX0 * 64;                             // [4 waves][2 tiles][8 chunks][64]  layer 1 candidate operands
     float* biasl = reinterpret_cast<float*>(wc1 + 4 * 2 * 8 * 64); // [NL][3][128]
-    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + NL * 3 * H));
+    EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + NL * 3 * H));
+    if constexpr (WINDOW) epi.cwords = reinterpret_cast<int8_t*>(reinterpret_cast<char*>(biasl + NL * 3 * H) + kEpilogueLdsBytes);
 
     constexpr int KC0 = KX0 + 4, KC1 = 8;
     // ---- LDS init (all eight waves): biases, zeroed mel staging, layer 1's candidate operands, initial state -------
@@ -502,6 +505,12 @@ gru_stack_bf16_ls(const GruBf16Params p) {
                 *reinterpret_cast<f32x4*>(p.state_out + ((size_t)layer * p.B + b) * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
         }
         __syncthreads();         // every wave is done with this group's LDS state before the next group's is written
+        if constexpr (WINDOW) {
+            // detector.py:195-209 for this group's 16 streams (all eight waves keep the barriers, four work): the call's
+            // frame words wait in epi.cwords, the scratch is hb | rhb
+            window_tail(p.epi.win, p.B, group * kStreamsPerGroup, T, epi.cwords, reinterpret_cast<char*>(hb), tid);
+            __syncthreads();
+        }
     };
     const f32x4* bl = reinterpret_cast<const f32x4*>(biasl + layer * 3 * H);
     // the epilogue's barriers are workgroup barriers: layer 0's waves keep step with them
@@ -753,8 +762,8 @@ gru_stack_bf16_ls(const GruBf16Params p) {
     }
 }
 
-size_t gru_bf16_ls_lds_bytes(int kx0) {
-    return (size_t)(2 * 2 * 4 * 64 + kx0 * 64 + 4 * 2 * 8 * 64) * 16 + (size_t)2 * 3 * 128 * 4 + kEpilogueLdsBytes;
+size_t gru_bf16_ls_lds_bytes(int kx0, bool window = false) {
+    return (size_t)(2 * 2 * 4 * 64 + kx0 * 64 + 4 * 2 * 8 * 64) * 16 + (size_t)2 * 3 * 128 * 4 + kEpilogueLdsBytes + (window ? kWinTailWordsBytes : 0);
 }
 
 size_t gru_bf16_lds_bytes(int kx0, int nl) {
@@ -778,12 +787,12 @@ static hipError_t launch_bf16(const GruBf16Params& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int KX0>
+template <int KX0, bool WINDOW = false>
 static hipError_t launch_bf16_ls(const GruBf16Params& p, hipStream_t st) {
-    const size_t lds = gru_bf16_ls_lds_bytes(KX0);
+    const size_t lds = gru_bf16_ls_lds_bytes(KX0, WINDOW);
     static LdsGrant granted;
     {
-        const hipError_t e = grant_dynamic_lds(gru_stack_bf16_ls<KX0>, granted, lds);
+        const hipError_t e = grant_dynamic_lds(gru_stack_bf16_ls<KX0, WINDOW>, granted, lds);
         if (e != hipSuccess) return e;
     }
     const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
@@ -797,7 +806,7 @@ static hipError_t launch_bf16_ls(const GruBf16Params& p, hipStream_t st) {
             cu_cache[dev].store(cus, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((gru_stack_bf16_ls<KX0>), dim3(groups < cus ? groups : cus), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((gru_stack_bf16_ls<KX0, WINDOW>), dim3(groups < cus ? groups : cus), dim3(512), lds, st, p);
     return hipGetLastError();
 }
 
@@ -810,6 +819,7 @@ const char* gru_stack_bf16_kernel_name(int kx0, int nl) {
     if (nl == 2) return kx0 == 1 ? "gru_stack_bf16<1, 2> (both layers, one launch, 4 waves)" : "gru_stack_bf16<2, 2> (both layers, one launch, 4 waves)";
     return kx0 == 1 ? "gru_stack_bf16<1, 1>" : "gru_stack_bf16<2, 1>";
 }
+bool gru_stack_bf16_takes_window(int kx0, int nl) { return nl == 2 && !bf16_four_waves() && (kx0 == 1 || kx0 == 2); }
 bool gru_bf16_vgpr_form() {
 #ifdef KWS_BF16_VGPR_FORM
     return true;
@@ -821,6 +831,12 @@ hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStr
     if (p.T <= 0 || p.B <= 0) return hipSuccess;   // the kernels prefetch frame min(t, T-1): nothing to run, nothing to read
     // two layers: the layer-specialised 8-wave kernel (KWS_BF16_WAVES=4 keeps the 4-wave kernel for A/B)
     const bool four = bf16_four_waves();
+    if (p.epi.win.tab != nullptr) {           // with the window tail: the 8-wave kernel only (gru_stack_bf16_takes_window)
+        if (nl != 2 || four || p.seq_len) return hipErrorInvalidValue;
+        if (kx0 == 1) return launch_bf16_ls<1, true>(p, st);
+        if (kx0 == 2) return launch_bf16_ls<2, true>(p, st);
+        return hipErrorInvalidValue;
+    }
     if (nl == 2 && !four) {
         if (kx0 == 1) return launch_bf16_ls<1>(p, st);
         if (kx0 == 2) return launch_bf16_ls<2>(p, st);

@@ -115,6 +115,7 @@ struct EpilogueLds {
     float* lring;
     int* words;
     int* carry;
+    int8_t* cwords;     // kernels instantiated with the window tail: [kWinTailMaxFrames][16] frame words of the whole call; else nullptr
 };
 constexpr size_t kEpilogueLdsBytes = (4 * 16 * 8 + kRingFrames * 16 * 8) * 4 + kRingFrames * 16 * 4 + 2 * 16 * 4;
 __device__ __forceinline__ EpilogueLds epilogue_carve(char* base) {
@@ -123,6 +124,7 @@ __device__ __forceinline__ EpilogueLds epilogue_carve(char* base) {
     e.lring = e.pstage + 4 * 16 * 8;
     e.words = reinterpret_cast<int*>(e.lring + kRingFrames * 16 * 8);
     e.carry = e.words + kRingFrames * 16;
+    e.cwords = nullptr;
     return e;
 }
 
@@ -197,6 +199,7 @@ __device__ __forceinline__ void epilogue_flush(const GruLayerParams& p, const Ep
     }
     if (!(best > p.decode_thres)) word = -1;
     e.words[f * 16 + s] = word;
+    if (e.cwords != nullptr && f < n) e.cwords[(t0 + f) * 16 + s] = (int8_t)word;      // the call's words wait for the window tail
     const bool mine = b < p.B && f < n;
     const size_t row = (size_t)b * (p.t_stride ? p.t_stride : p.T) + (t0 + f);
     if (mine) {

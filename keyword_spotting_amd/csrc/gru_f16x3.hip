@@ -43,6 +43,7 @@
 #include <cstdlib>
 
 #include "gru_device.h"
+#include "window_device.h"
 
 namespace kws {
 
@@ -138,19 +139,22 @@ __device__ long long* g_timing = nullptr;
 
 }  // namespace
 
-size_t gru_f16x3_lds_bytes(int kx, bool first, bool last) {
+size_t gru_f16x3_lds_bytes(int kx, bool first, bool last, bool window = false) {
     size_t n = 2 * 4 * 2 * 64 * 16;                      // hb, rhb
     n += (size_t)(first ? 3 : 2) * kx * 2 * 64 * 16;     // xsb: three slots in the first layer, two above
     if (first) n += 512;                                 // dump row for the idle lanes' mel stores
     if (!first) n += (size_t)4 * 7 * 4 * 64 * 16;        // gate x-part operands streamed from LDS: 7 groups of 4 per wave
     n += 3 * 128 * 4 + 16 * 4;                           // biases
     if (last) n += kEpilogueLdsBytes;
+    if (window) n += kWinTailWordsBytes;
     return n;
 }
 
-template <int KX, bool FIRST, bool LAST, bool MASKED>
+// WINDOW (LAST only): the decode-window step of the stream manager rides at the end of every group (window_device.h)
+template <int KX, bool FIRST, bool LAST, bool MASKED, bool WINDOW = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gru_layer_f16x3(const GruF16Params p) {
+    static_assert(!WINDOW || LAST, "the window tail belongs to the last layer");
     constexpr int H = 128, KC = KX + 4;
     constexpr int NG = lds_groups<KX, FIRST>();          // LDS-resident operand groups per wave (0 or 7)
     constexpr int NX = 18 * KX;                          // MFMAs of one frame's x-part
@@ -168,7 +172,8 @@ gru_layer_f16x3(const GruF16Params p) {
     u32x4* xsb = rhb + 4 * 2 * 64;                            // [NS slots][KX][2][64]
     u32x4* wul = xsb + NS * KX * 2 * 64 + (FIRST ? 32 : 0);                      // !FIRST: [4 waves][NG groups][tile j][hi|lo][64]
     float* biasl = reinterpret_cast<float*>(wul + 4 * NG * 4 * 64);    // [3][128] + [16] class bias
-    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * H + 16));      // LAST only
+    EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * H + 16));      // LAST only
+    if constexpr (WINDOW) epi.cwords = reinterpret_cast<int8_t*>(reinterpret_cast<char*>(biasl + 3 * H + 16) + kEpilogueLdsBytes);
 
     // ---- operands: [tile j][gate q][chunk][hi|lo]; table p.w is [8 tiles][3][KC][2][64 lanes] x 16 B, x chunks first ----
     const u32x4* wt_tab = reinterpret_cast<const u32x4*>(p.w);
@@ -669,6 +674,13 @@ gru_layer_f16x3(const GruF16Params p) {
             for (int j = 0; j < 2; ++j)
                 *reinterpret_cast<f32x4*>(p.state_out + (size_t)b * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
         }
+        if constexpr (WINDOW) {
+            // detector.py:195-209 for this group's 16 streams: the call's frame words wait in epi.cwords (final flush), the
+            // scratch is hb | rhb, which nobody reads after the last frame
+            __syncthreads();
+            window_tail(p.epi.win, p.B, group * kStreamsPerGroup, T, epi.cwords, reinterpret_cast<char*>(hb), tid);
+            __syncthreads();
+        }
     }
 }
 
@@ -682,12 +694,12 @@ bool gru_f16x3_vgpr_form() {
 
 bool gru_f16x3_supported(int hidden, int n_mel) { return hidden == 128 && n_mel % 4 == 0 && n_mel >= 4 && n_mel <= 64; }
 
-template <int KX, bool FIRST, bool LAST, bool MASKED>
+template <int KX, bool FIRST, bool LAST, bool MASKED, bool WINDOW = false>
 static hipError_t launch_f16x3m(const GruF16Params& p, hipStream_t st) {
-    const size_t lds = gru_f16x3_lds_bytes(KX, FIRST, LAST);
+    const size_t lds = gru_f16x3_lds_bytes(KX, FIRST, LAST, WINDOW);
     static LdsGrant granted;
     {
-        const hipError_t e = grant_dynamic_lds(gru_layer_f16x3<KX, FIRST, LAST, MASKED>, granted, lds);
+        const hipError_t e = grant_dynamic_lds(gru_layer_f16x3<KX, FIRST, LAST, MASKED, WINDOW>, granted, lds);
         if (e != hipSuccess) return e;
     }
     const int groups = (p.B + kStreamsPerGroup - 1) / kStreamsPerGroup;
@@ -709,7 +721,7 @@ static hipError_t launch_f16x3m(const GruF16Params& p, hipStream_t st) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timing), &tbuf, sizeof(tbuf));
     }
 #endif
-    hipLaunchKernelGGL((gru_layer_f16x3<KX, FIRST, LAST, MASKED>), dim3(groups < cus ? groups : cus), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gru_layer_f16x3<KX, FIRST, LAST, MASKED, WINDOW>), dim3(groups < cus ? groups : cus), dim3(256), lds, st, p);
 #ifdef KWS_F16_TIMING
     if (getenv("KWS_F16_TIMING")) {
         (void)hipDeviceSynchronize();
@@ -730,6 +742,10 @@ static hipError_t launch_f16x3m(const GruF16Params& p, hipStream_t st) {
 // the copy-through past seq_len costs 16 VALU instructions per frame: its own instantiation, used only when lengths are given
 template <int KX, bool FIRST, bool LAST>
 static hipError_t launch_f16x3(const GruF16Params& p, hipStream_t st) {
+    if constexpr (LAST) {
+        // the window tail exists without the length mask only: the stream manager never passes seq_len (kws_api.hip checks)
+        if (p.epi.win.tab != nullptr) return p.seq_len ? hipErrorInvalidValue : launch_f16x3m<KX, FIRST, LAST, false, true>(p, st);
+    }
     return p.seq_len ? launch_f16x3m<KX, FIRST, LAST, true>(p, st) : launch_f16x3m<KX, FIRST, LAST, false>(p, st);
 }
 

@@ -19,15 +19,19 @@
 //   * x-part MFMAs of frame t+1 are issued behind frame t's two barriers (software pipeline), so
 //     the LDS exchange latency overlaps independent matrix work.
 #include "gru_device.h"
+#include "window_device.h"
 
 namespace kws {
 
 // ------------------------------------------------------------------------------------------------
 // Resident kernel, H = 128.  KCX = x-part k-chunks (ceil(I/4) for the first layer, 32 above it).
 // ------------------------------------------------------------------------------------------------
-template <int KCX, bool FIRST, bool LAST>
+// WINDOW (instantiated for the upper last layer only): the decode-window step of the stream manager rides at the end of
+// every group (window_device.h); every other instantiation compiles exactly as without the parameter.
+template <int KCX, bool FIRST, bool LAST, bool WINDOW = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gru_layer_resident(const GruLayerParams p) {
+    static_assert(!WINDOW || (LAST && !FIRST), "the window tail belongs to the last layer of a stack");
     constexpr int H = 128, NT = 8, KCH = 32;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,7 +51,8 @@ gru_layer_resident(const GruLayerParams p) {
     f32x4* hbuf = reinterpret_cast<f32x4*>(smem);       // [NT][64]  h_{t-1}, xl layout
     f32x4* rhbuf = hbuf + NT * 64;                       // [NT][64]  r (.) h_{t-1}
     f32x4* wlds = rhbuf + NT * 64;                       // [4 waves][KCX][64] gate x-part: {r0,u0,r1,u1}
-    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(wlds + 4 * KCX * 64));   // LAST only
+    EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(wlds + 4 * KCX * 64));   // LAST only
+    if constexpr (WINDOW) epi.cwords = reinterpret_cast<int8_t*>(reinterpret_cast<char*>(wlds + 4 * KCX * 64) + kEpilogueLdsBytes);
     // FIRST only: one frame of mel for the group, [16 streams x 4 lane groups][kXsStride] floats, row
     // (4s+g) holds x[s][4*kc+g] for kc = 0..KCX-1 -- each lane's B operands are contiguous
     constexpr int kXsStride = xs_stride(KCX);       // 4 * odd: rows 16 apart in one ds_read_b128 group spread over the banks
@@ -428,6 +433,11 @@ gru_layer_resident(const GruLayerParams p) {
             *reinterpret_cast<f32x4*>(p.state_out + (size_t)b * H + (2 * w + j) * 16 + 4 * g) = hreg[j];
     }
     __syncthreads();             // every wave is done with this group's LDS state before the next group overwrites it
+    if constexpr (WINDOW) {
+        // detector.py:195-209 for this group's 16 streams: the call's frame words wait in epi.cwords, the scratch is hbuf | rhbuf
+        window_tail(p.win, p.B, group * kStreamsPerGroup, T, epi.cwords, reinterpret_cast<char*>(hbuf), tid);
+        __syncthreads();
+    }
     }
 }
 
@@ -816,8 +826,14 @@ static hipError_t launch_resident(K kernel, const GruLayerParams& p, size_t lds,
     return hipGetLastError();
 }
 
+bool gru_resident_takes_window(bool first, bool last) { return last && !first; }
+
 hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool last, hipStream_t st) {
     const size_t lds = resident_lds_bytes(p.KCX, first, last);
+    if (p.win.tab != nullptr) {               // with the window tail: the last layer of a stack only
+        if (!gru_resident_takes_window(first, last) || p.seq_len) return hipErrorInvalidValue;
+        return launch_resident(gru_layer_resident<32, false, true, true>, p, lds + kWinTailWordsBytes, st);
+    }
 #define KWS_RES(KCX_, F_, L_) return launch_resident(gru_layer_resident<KCX_, F_, L_>, p, lds, st)
     if (first) {
         if (p.KCX == 8) { if (last) KWS_RES(8, true, true); else KWS_RES(8, true, false); }

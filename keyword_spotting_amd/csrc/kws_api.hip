@@ -139,14 +139,14 @@ struct kws_model {
     // kernel the last kws_step launched per profiling slot, as a small tag: the name is only formatted when somebody asks
     // (kws_last_launch, kws_selftest) -- not on the launch path, where a 22-frame call is ~100 us of device time
     enum LaunchFamily : uint8_t { kNone = 0, kBf16Stack, kF16x3, kPipelined, kOctbit, kOctbitFc, kResident, kGeneric };
-    struct LaunchTag { uint8_t family = kNone, kx = 0, first = 0, last = 0; };
+    struct LaunchTag { uint8_t family = kNone, kx = 0, first = 0, last = 0, window = 0; };
     LaunchTag launch_tag[8];
     std::string launch_name(int slot) const {
         const LaunchTag& t = launch_tag[slot];
         char nm[96];
         nm[0] = 0;
         switch (t.family) {
-            case kBf16Stack: return kws::gru_stack_bf16_kernel_name(bf_kx0, cfg.num_layers);
+            case kBf16Stack: break;
             case kF16x3: snprintf(nm, sizeof(nm), "gru_layer_f16x3<%d, %s, %s>", t.kx, t.first ? "true" : "false", t.last ? "true" : "false"); break;
             case kPipelined: snprintf(nm, sizeof(nm), "gru_stack_generic_pipelined<%d> (all %d layers, one launch)", t.kx, cfg.num_layers); break;
             case kOctbit: snprintf(nm, sizeof(nm), "gru_layer_octbit_kernel"); break;
@@ -155,7 +155,9 @@ struct kws_model {
             case kGeneric: snprintf(nm, sizeof(nm), "gru_layer_generic<%d, %s, %s>", t.kx, t.first ? "true" : "false", t.last ? "true" : "false"); break;
             default: break;
         }
-        return nm;
+        std::string out = t.family == kBf16Stack ? std::string(kws::gru_stack_bf16_kernel_name(bf_kx0, cfg.num_layers)) : std::string(nm);
+        if (t.window) out += " + window tail";          // the stream manager's decode-window step rode in this launch
+        return out;
     }
 };
 
@@ -164,6 +166,15 @@ struct kws_window {
     float thres = 0.f;
     int8_t* words = nullptr;
     int *lens = nullptr, *head = nullptr, *count = nullptr;
+    // the incremental form (kws_window_step_incremental, kws_stream_feed): a summary per queued chunk instead of its frames
+    // (window_device.h); a state of its own -- a window is driven through one of the two entry points, not both
+    uint8_t* inc_tab = nullptr;      // [B][nq][16]
+    uint32_t* inc_meta = nullptr;    // [B][nq]
+    int *inc_head = nullptr, *inc_count = nullptr;
+    uint8_t* inc_delta_dev = nullptr;   // [256] label matcher of the bound label
+    uint8_t inc_delta[256] = {0};
+    char inc_label[17] = {0};
+    bool inc_bound = false;
 };
 
 struct kws_stream {
@@ -950,10 +961,36 @@ static int step_overlapped(kws_handle h, const float* mel, const float* state_in
     return KWS_OK;
 }
 
+// Can the last layer's launch of a (B, T) step on this handle take the window tail along?  (kws_stream_feed asks before it
+// hands one to step_impl; the kernels without a tail instantiation -- generic, pipelined, overlapped, int8, single-layer fp32,
+// 4-wave bf16 -- are followed by window_inc_kernel instead.)
+static bool step_takes_window(kws_handle h, int B, int T, int window_chunks) {
+    const kws_config& c = h->cfg;
+    if (T < 1 || T > kws::kWinTailMaxFrames || window_chunks > kws::kWinTailMaxChunks) return false;
+    if (c.precision == KWS_BF16) return kws::gru_stack_bf16_takes_window(h->bf_kx0, c.num_layers);
+    if (c.precision == KWS_F16X3) return true;
+    if (c.precision != KWS_FP32 || pipeline_eligible(h, B) || overlap_eligible(h, B, T)) return false;
+    const LayerDev& Ld = h->layers[c.num_layers - 1];
+    const bool resident = h->kernel_kind == KWS_KERNEL_RESIDENT || (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok);
+    return resident && kws::gru_resident_takes_window(c.num_layers == 1, true);
+}
+
+static int step_impl(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
+                     float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
+                     int32_t* prev_word, float decode2_thres, int B, int T, void* stream, const kws::WindowTail* wt);
+
 int kws_step(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
              float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
              int32_t* prev_word, float decode2_thres, int B, int T, void* stream) {
+    return step_impl(h, mel, state_in, logits, softmax, state_out, seq_len, reset_mask, tokens, prev_word, decode2_thres, B, T, stream, nullptr);
+}
+
+// wt: the stream manager's decode window, to ride at the end of the last layer's launch (step_takes_window said yes)
+static int step_impl(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
+                     float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
+                     int32_t* prev_word, float decode2_thres, int B, int T, void* stream, const kws::WindowTail* wt) {
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (wt && (seq_len || !step_takes_window(h, B, T, wt->nq))) return fail(KWS_ERR_UNSUPPORTED, "internal: this step cannot take a window tail");
     if (B < 0 || T < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative B=%d or T=%d", B, T);
     if (B == 0) return KWS_OK;   // nothing to advance (empty tensors have null data pointers)
     if (!state_in || !state_out) return fail(KWS_ERR_INVALID_ARGUMENT, "state_in/state_out must not be null");
@@ -1019,6 +1056,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         bp.epi.logits = logits; bp.epi.softmax = softmax; bp.epi.tokens = tokens; bp.epi.prev_word = prev_word;
         bp.epi.decode_thres = decode2_thres; bp.epi.value_clip = c.value_clip; bp.epi.use_relu = c.use_relu;
         bp.epi.B = B; bp.epi.T = T; bp.epi.C = c.num_classes;
+        if (wt) bp.epi.win = *wt;
         bp.B = B; bp.T = T; bp.I = c.n_mel; bp.L = L;
         hipEvent_t ea = nullptr, eb = nullptr;
         if (h->profiling) {
@@ -1030,7 +1068,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         }
         hipError_t e = kws::launch_gru_stack_bf16(bp, h->bf_kx0, L, st);
         if (e != hipSuccess) return hip_fail(e, "launch gru_stack_bf16");
-        h->launch_tag[0] = {kws_model::kBf16Stack, 0, 0, 0};
+        h->launch_tag[0] = {kws_model::kBf16Stack, 0, 0, 0, (uint8_t)(wt != nullptr)};
         for (int l = 1; l < L; ++l) h->launch_tag[l] = {};
         if (h->profiling) {
             KWS_HIP(hipEventRecord(eb, st));
@@ -1060,6 +1098,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             fp.epi.logits = logits; fp.epi.softmax = softmax; fp.epi.tokens = tokens; fp.epi.prev_word = prev_word;
             fp.epi.decode_thres = decode2_thres; fp.epi.value_clip = c.value_clip; fp.epi.use_relu = c.use_relu;
             fp.epi.B = B; fp.epi.T = T; fp.epi.C = c.num_classes;
+            if (wt && last) fp.epi.win = *wt;
             fp.B = B; fp.T = T; fp.I = h->layers[l].in_dim;
             hipEvent_t ea = nullptr, eb = nullptr;
             if (h->profiling) {
@@ -1071,7 +1110,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             }
             hipError_t e = kws::launch_gru_layer_f16x3(fp, first, last, st);
             if (e != hipSuccess) return hip_fail(e, "launch gru_layer_f16x3");
-            h->launch_tag[l] = {kws_model::kF16x3, (uint8_t)(first ? h->f16_kx0 : 4), first, last};
+            h->launch_tag[l] = {kws_model::kF16x3, (uint8_t)(first ? h->f16_kx0 : 4), first, last, (uint8_t)(wt != nullptr && last)};
             if (h->profiling) {
                 KWS_HIP(hipEventRecord(eb, st));
                 h->pending.push_back({l, ea, eb});
@@ -1129,6 +1168,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
         p.use_relu = c.use_relu;
         p.B = B; p.T = T; p.I = Ld.in_dim; p.C = c.num_classes;
         p.KCX = resident ? Ld.kcx_res : Ld.kcx_gen;
+        if (wt && last) p.win = *wt;
 
         if (pipelined) {
             p.ready_in = first ? nullptr : h->pipe_ready + (size_t)(l - 1) * h->pipe_groups;
@@ -1173,7 +1213,7 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
             h->launch_tag[l] = {kws_model::kPipelined, (uint8_t)(H / 64), 0, 0};
             for (int k = 0; k < l; ++k) h->launch_tag[k] = {};
         } else if (int8 && h->oct[l].quantised) h->launch_tag[l] = {(uint8_t)(l == L - 1 ? kws_model::kOctbitFc : kws_model::kOctbit), 0, 0, 0};
-        else if (resident) h->launch_tag[l] = {kws_model::kResident, (uint8_t)p.KCX, first, last};
+        else if (resident) h->launch_tag[l] = {kws_model::kResident, (uint8_t)p.KCX, first, last, (uint8_t)(wt != nullptr && last)};
         else h->launch_tag[l] = {kws_model::kGeneric, (uint8_t)(H / 64), first, last};
         if (int8 && l == L - 1) {
             kws::OctbitFcParams fp;
@@ -1220,6 +1260,14 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres,
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->lens), (size_t)B * max_chunks * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->head), (size_t)B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->count), (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_tab), (size_t)B * max_chunks * 16);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_meta), (size_t)B * max_chunks * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_head), (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_count), (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_delta_dev), 256);
+    if (e == hipSuccess) e = hipMemset(wnd->inc_tab, 0, (size_t)B * max_chunks * 16);
+    if (e == hipSuccess) e = hipMemset(wnd->inc_meta, 0, (size_t)B * max_chunks * sizeof(uint32_t));
+    if (e == hipSuccess) e = kws::launch_window_reset(B, wnd->inc_head, wnd->inc_count, nullptr);
     if (e == hipSuccess) e = kws::launch_window_reset(B, wnd->head, wnd->count, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { kws_window_destroy(wnd); return hip_fail(e, "kws_window_create"); }
@@ -1236,6 +1284,11 @@ int kws_window_destroy(kws_window_handle h) {
     if (h->lens) hipFree(h->lens);
     if (h->head) hipFree(h->head);
     if (h->count) hipFree(h->count);
+    if (h->inc_tab) hipFree(h->inc_tab);
+    if (h->inc_meta) hipFree(h->inc_meta);
+    if (h->inc_head) hipFree(h->inc_head);
+    if (h->inc_count) hipFree(h->inc_count);
+    if (h->inc_delta_dev) hipFree(h->inc_delta_dev);
     delete h;
     return KWS_OK;
 }
@@ -1259,6 +1312,67 @@ int kws_window_step(kws_window_handle h, const float* softmax, int T, const uint
     p.thres = h->thres; p.B = h->B; p.T = T; p.C = h->C; p.nq = h->nq; p.tmax = h->tmax_pad;
     hipError_t e = kws::launch_window_step(p, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "launch window_step");
+    return KWS_OK;
+}
+
+// The label matcher of the incremental window: KMP automaton over emitted words, delta[q * 16 + w] = digits of the label
+// matched after reading word w (1..15) with q matched before (q < len); words the label does not contain lead to 0.
+static void window_label_delta(const char* label, int n, uint8_t* delta) {
+    memset(delta, 0, 256);
+    for (int q = 0; q < n; ++q)
+        for (int w = 1; w < 16; ++w) {
+            int k = q + 1;                       // longest k with label[0..k) a suffix of label[0..q) + w
+            for (; k > 0; --k) {
+                if (label[k - 1] - '0' != w) continue;
+                bool ok = true;
+                for (int i = 0; i < k - 1 && ok; ++i) ok = label[i] == label[q - (k - 1) + i];
+                if (ok) break;
+            }
+            delta[q * 16 + w] = (uint8_t)k;
+        }
+}
+
+// Binds `label` to the window's incremental state (the queued summaries are label-specific).  The first binding uploads the
+// matcher (synchronises); the same label again is free; another label while chunks may be queued is refused.
+static int window_bind_label(kws_window* w, const char* label) {
+    const int n = (int)strlen(label);
+    if (n > 16) return fail(KWS_ERR_INVALID_ARGUMENT, "label longer than 16 digits");
+    for (int i = 0; i < n; ++i)
+        if (label[i] < '1' || label[i] > '9') return fail(KWS_ERR_INVALID_ARGUMENT, "label must be digits 1..9, got '%s'", label);
+    if (w->inc_bound) {
+        if (strcmp(w->inc_label, label) == 0) return KWS_OK;
+        return fail(KWS_ERR_INVALID_ARGUMENT, "the window's incremental state was built for label '%s'; it cannot continue with '%s' "
+                    "(create another window, or use kws_window_step, which re-scans the frames)", w->inc_label, label);
+    }
+    window_label_delta(label, n, w->inc_delta);
+    KWS_HIP(hipMemcpy(w->inc_delta_dev, w->inc_delta, 256, hipMemcpyHostToDevice));
+    memcpy(w->inc_label, label, n + 1);
+    w->inc_bound = true;
+    return KWS_OK;
+}
+
+static kws::WindowTail window_tail_params(kws_window* w, const uint8_t* clear_before, int32_t* hit, uint8_t* restart) {
+    kws::WindowTail t;
+    memset(&t, 0, sizeof(t));
+    t.tab = w->inc_tab; t.meta = w->inc_meta; t.head = w->inc_head; t.count = w->inc_count; t.delta = w->inc_delta_dev;
+    t.clear_before = clear_before; t.hit = hit; t.restart = restart; t.nq = w->nq; t.n_label = (int)strlen(w->inc_label);
+    return t;
+}
+
+int kws_window_step_incremental(kws_window_handle h, const float* softmax, int T, const uint8_t* clear_before, const char* label,
+                                int32_t* hit, uint8_t* restart, void* stream) {
+    if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
+    if (T < 0 || T > h->tmax) return fail(KWS_ERR_INVALID_ARGUMENT, "T=%d outside [0,%d]", T, h->tmax);
+    if (!hit || (!softmax && T > 0) || !label) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    const int rc = window_bind_label(h, label);
+    if (rc != KWS_OK) return rc;
+    kws::WindowIncParams p;
+    memset(&p, 0, sizeof(p));
+    p.win = window_tail_params(h, clear_before, hit, restart);
+    memcpy(p.delta, h->inc_delta, 256);
+    p.softmax = softmax; p.thres = h->thres; p.B = h->B; p.T = T; p.C = h->C;
+    hipError_t e = kws::launch_window_inc(p, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch window_inc");
     return KWS_OK;
 }
 
@@ -1494,7 +1608,8 @@ int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->silent), (size_t)B);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->reset), (size_t)B);
     if (e != hipSuccess) { kws_stream_destroy(s); return hip_fail(e, "hipMalloc(stream buffers)"); }
-    const int rc = kws_reserve(model, B, tmax);            // the GRU step of a chunk never allocates afterwards
+    int rc = kws_reserve(model, B, tmax);            // the GRU step of a chunk never allocates afterwards
+    if (rc == KWS_OK) rc = window_bind_label(window, s->label);      // the window's summaries are built for this label
     if (rc != KWS_OK) { kws_stream_destroy(s); return rc; }
     *out = s;
     return KWS_OK;
@@ -1543,7 +1658,7 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
         if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
         int rc = kws_step(h->model, nullptr, h->state, nullptr, nullptr, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, 0, st);
         if (rc != KWS_OK) return rc;
-        rc = kws_window_step(h->win, nullptr, 0, h->silent, h->label, hit, h->restart, st);
+        rc = kws_window_step_incremental(h->win, nullptr, 0, h->silent, h->label, hit, h->restart, st);
         if (rc != KWS_OK) return rc;
         h->n_carry = total; h->cur ^= 1;
         return KWS_OK;
@@ -1564,10 +1679,22 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
         rc = kws_frontend_run_carry(h->fe, h->n_carry ? carry : nullptr, h->n_carry, chunk, n, B, h->mel, nullptr, 0, st);
         if (rc != KWS_OK) return rc;
     }
-    rc = kws_step(h->model, h->mel, h->state, nullptr, h->softmax, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, T, st);
+    rc = window_bind_label(h->win, h->label);          // (bound at kws_stream_create; refuses a window that went on with another label)
     if (rc != KWS_OK) return rc;
-    rc = kws_window_step(h->win, h->softmax, T, h->silent, h->label, hit, h->restart, st);
-    if (rc != KWS_OK) return rc;
+    if (step_takes_window(h->model, B, T, h->win->nq)) {
+        // THREE launches per chunk (two for the bf16 stack): the decode-window step (prob_queue.add, ctc_decode2 over the
+        // window, ctc_predict, clear + restart on a hit: detector.py:195-209) rides at the end of the last layer's launch, on
+        // the frame words its flush has just produced -- no softmax round trip, no fourth launch.  The window's threshold
+        // is the fused decoder's (ctc_decode2's frame rule, utils/prediction.py:74)
+        const kws::WindowTail wt = window_tail_params(h->win, h->silent, hit, h->restart);
+        rc = step_impl(h->model, h->mel, h->state, nullptr, nullptr, h->state, nullptr, h->reset, nullptr, nullptr, h->win->thres, B, T, st, &wt);
+        if (rc != KWS_OK) return rc;
+    } else {
+        rc = kws_step(h->model, h->mel, h->state, nullptr, h->softmax, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, T, st);
+        if (rc != KWS_OK) return rc;
+        rc = kws_window_step_incremental(h->win, h->softmax, T, h->silent, h->label, hit, h->restart, st);
+        if (rc != KWS_OK) return rc;
+    }
     h->n_carry = keep; h->cur ^= 1;
     return KWS_OK;
 }

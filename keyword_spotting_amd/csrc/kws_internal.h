@@ -39,6 +39,24 @@ inline hipError_t grant_dynamic_lds(K kernel, LdsGrant& cache, size_t lds) {
 // lane = 16*g + s, component r  <->  unit 16*n + 4*g + r of stream s.  This is at once the MFMA
 // 16x16x4 C/D register image of tile n and, read back as float4, the B operand of the four
 // k-chunks 4n..4n+3 -- so hidden state never needs a cross-lane transpose.
+// The incremental decode window of a stream manager (window_device.h), run as the tail of the last layer's launch or by
+// window_inc_kernel.  tab == nullptr: none.
+struct WindowTail {
+    uint8_t* tab;               // [B][nq][16]  per queued chunk: matcher state after its frames 1..n-1 when entered in state q
+    uint32_t* meta;             // [B][nq]      bit 16: the chunk has frames; bits 0-7: first frame's word + 1; bits 8-15: last frame's word + 1
+    int* head;                  // [B]
+    int* count;                 // [B]
+    const uint8_t* delta;       // [16 states][16 words] label matcher (KMP automaton), device memory
+    const uint8_t* clear_before;// [B] or null
+    int32_t* hit;               // [B]
+    uint8_t* restart;           // [B] or null
+    int nq, n_label;
+};
+constexpr int kWinTailMaxFrames = 64;   // chunk lengths the fused tail takes (its per-frame words wait in LDS): longer -> window_inc_kernel
+constexpr int kWinTailMaxChunks = 32;   // window lengths the fused tail takes (the rings of 16 streams are staged in LDS)
+constexpr size_t kWinTailWordsBytes = (size_t)kWinTailMaxFrames * 16;
+__host__ __device__ inline size_t window_tail_scratch_bytes(int nq) { return 512 + (size_t)16 * nq * 20; }
+
 struct GruLayerParams {
     // weights (device, packed by pack.cpp)
     const float* wx;        // x-part fragments  [NT][3][KCX/4][64][4]; resident first layer: [NT][3][KCX][64]
@@ -70,6 +88,9 @@ struct GruLayerParams {
     const int* ready_in;
     int* ready_out;
     int* pipe_error;
+    // LAST, kernels instantiated with the window tail only (kws_stream_feed): the decode-window step of detector.py:195-209
+    // for the group's 16 streams, after their last frame (kept at the end: every other field keeps its offset)
+    WindowTail win;
 };
 struct GruStackParams {
     GruLayerParams layer[8];
@@ -93,7 +114,8 @@ struct GruBf16Params {
     int B, T, I, L;
 };
 bool gru_bf16_supported(int hidden, int n_mel, int layers);
-hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st);
+hipError_t launch_gru_stack_bf16(const GruBf16Params& p, int kx0, int nl, hipStream_t st);    // p.epi.win.tab != null: with the window tail
+bool gru_stack_bf16_takes_window(int kx0, int nl);          // the launch above has a window-tail instantiation for this shape
 const char* gru_stack_bf16_kernel_name(int kx0, int nl);   // the kernel launch_gru_stack_bf16 picks (KWS_BF16_WAVES aware)
 bool gru_bf16_vgpr_form();                                  // built with -mllvm -amdgpu-mfma-vgpr-form=1 (csrc/Makefile)
 
@@ -114,7 +136,7 @@ struct GruF16Params {
     int B, T, I;
 };
 bool gru_f16x3_supported(int hidden, int n_mel);
-hipError_t launch_gru_layer_f16x3(const GruF16Params& p, bool first, bool last, hipStream_t st);
+hipError_t launch_gru_layer_f16x3(const GruF16Params& p, bool first, bool last, hipStream_t st);    // last && p.epi.win.tab: with the window tail
 bool gru_f16x3_vgpr_form();                                 // gru_f16x3.hip built with -mllvm -amdgpu-mfma-vgpr-form=1 (csrc/Makefile)
 
 // int8 ("octbit") GRU layers and class projection (gru_octbit.hip)
@@ -166,6 +188,15 @@ struct WindowParams {
     int B, T, C, nq, tmax;
 };
 hipError_t launch_window_step(const WindowParams& p, hipStream_t st);
+// the incremental form (summaries per queued chunk, window_device.h): softmax [B][T][C] -> per-frame words -> window tail
+struct WindowIncParams {
+    WindowTail win;
+    uint8_t delta[256];       // by value: the standalone step takes the label per call
+    const float* softmax;
+    float thres;
+    int B, T, C;
+};
+hipError_t launch_window_inc(const WindowIncParams& p, hipStream_t st);
 hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st);
 
 // PCM -> mel front-end (frontend_kernels.hip)
@@ -201,7 +232,8 @@ hipError_t launch_carry_tail(const float* carry, int n_carry, const float* chunk
 // launchers (gru_kernels.hip)
 bool gru_resident_supported(int hidden, int in_dim, bool first);
 int gru_resident_kcx(int in_dim, bool first);
-hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool last, hipStream_t st);
+hipError_t launch_gru_layer_resident(const GruLayerParams& p, bool first, bool last, hipStream_t st);    // p.win.tab != null: with the window tail
+bool gru_resident_takes_window(bool first, bool last);
 hipError_t launch_gru_layer_generic(const GruLayerParams& p, int hidden, bool first, bool last,
                                     hipStream_t st);
 

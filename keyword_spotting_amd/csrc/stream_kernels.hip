@@ -7,6 +7,7 @@
 //   * on trigger: clear the window and request a state reset (detector.py:202-208) -> restart[b] = 1
 // One wave per stream (window_step_kernel below).
 #include "kws_internal.h"
+#include "window_device.h"
 
 namespace kws {
 
@@ -101,6 +102,32 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
     }
 }
 
+// The incremental window as a launch of its own (kws_window_step_incremental; kws_stream_feed where the last GRU layer's
+// kernel has no window tail: generic / pipelined / int8 kernels, chunks of more than 64 frames, zero-frame chunks).  One
+// workgroup = 16 streams, as the tail inside the GRU kernels: the frame rule of ctc_decode2 (utils/prediction.py:67,74-75)
+// over the chunk's softmax rows, then window_tail.
+__global__ void __launch_bounds__(256) window_inc_kernel(const WindowIncParams p) {
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    int8_t* cw = reinterpret_cast<int8_t*>(wlds);                              // [T][16]
+    char* scratch = wlds + (((size_t)p.T * 16 + 15) & ~(size_t)15);
+    uint8_t* dsrc = reinterpret_cast<uint8_t*>(scratch) + window_tail_scratch_bytes(p.win.nq);   // the by-value table, where the tail can load it from
+    const int tid = threadIdx.x, b0 = blockIdx.x * 16, C = p.C;
+    dsrc[tid] = p.delta[tid];
+    const int s = tid & 15, b = min(b0 + s, p.B - 1);
+    for (int t = tid >> 4; t < p.T; t += 16) {
+        const float* row = p.softmax + ((size_t)b * p.T + t) * C;
+        float best = row[1];
+        int arg = 0;
+        for (int c = 2; c < C - 1; ++c)
+            if (row[c] > best) { best = row[c]; arg = c - 1; }
+        cw[t * 16 + s] = (int8_t)(best > p.thres ? arg : -1);
+    }
+    __syncthreads();
+    WindowTail W = p.win;
+    W.delta = dsrc;                 // LDS address through the generic pointer
+    window_tail(W, p.B, b0, p.T, cw, scratch, tid);
+}
+
 __global__ void window_reset_kernel(int B, int* head, int* count) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) { head[b] = 0; count[b] = 0; }
@@ -108,6 +135,16 @@ __global__ void window_reset_kernel(int B, int* head, int* count) {
 
 hipError_t launch_window_step(const WindowParams& p, hipStream_t st) {
     hipLaunchKernelGGL(window_step_kernel, dim3(p.B), dim3(64), (size_t)2 * p.nq * p.tmax, st, p);
+    return hipGetLastError();
+}
+hipError_t launch_window_inc(const WindowIncParams& p, hipStream_t st) {
+    const size_t lds = (((size_t)p.T * 16 + 15) & ~(size_t)15) + window_tail_scratch_bytes(p.win.nq) + 256;
+    static LdsGrant granted;
+    if (lds > 48 * 1024) {
+        const hipError_t e = grant_dynamic_lds(window_inc_kernel, granted, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(window_inc_kernel, dim3((p.B + 15) / 16), dim3(256), lds, st, p);
     return hipGetLastError();
 }
 hipError_t launch_window_reset(int B, int* head, int* count, hipStream_t st) {

@@ -181,8 +181,8 @@ class HotwordDetector(object):
 class StreamManager(object):
     """The same loop with every per-stream decision on the device.  feed_pcm is ONE native call
     per chunk (kws_stream_feed: VAD gate -> front-end with sample carry -> GRU stack -> 15-chunk window with windowed
-    ctc_decode2 + ctc_predict, trigger -> clear + restart); feed takes mel chunks and chains kws_step and
-    kws_window_step itself.  No per-stream host work; results are identical to HotwordDetector
+    ctc_decode2 + ctc_predict, trigger -> clear + restart; the window step rides inside the last GRU layer's launch); feed
+    takes mel chunks and chains kws_step and kws_window_step_incremental itself.  No per-stream host work; results are identical to HotwordDetector
     (tests/test_gpu_detector.py, tests/test_gpu_frontend.py)."""
 
     def __init__(self, model, batch, window_chunks=15, max_frames=32, vad_thres=30, label=None, decode_thres=0.4):
@@ -237,8 +237,10 @@ class StreamManager(object):
                                state_out=self.state)
         sm = r["softmax"]
         with torch.cuda.device(dev):
-            _lib.check(self._lib.kws_window_step(self._win, _lib.ptr(sm), int(sm.shape[1]), _lib.ptr(silent), self.label,
-                                                 _lib.ptr(self.hit), _lib.ptr(self.restart), _lib.current_stream_ptr()))
+            # the incremental form of the window step: the state kws_stream_feed (feed_pcm) keeps, so mel-fed and PCM-fed
+            # chunks may alternate on one manager
+            _lib.check(self._lib.kws_window_step_incremental(self._win, _lib.ptr(sm), int(sm.shape[1]), _lib.ptr(silent), self.label,
+                                                             _lib.ptr(self.hit), _lib.ptr(self.restart), _lib.current_stream_ptr()))
         return self.hit
 
     def feed_pcm(self, pcm_chunk, frontend):
