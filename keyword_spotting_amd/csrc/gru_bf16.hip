@@ -14,6 +14,8 @@
 // launch with no inter-layer HBM scratch; activations, LDS exchange and barriers dominate.
 #include <cstdlib>
 
+#include <cstddef>
+
 #include "gru_device.h"
 #include "window_device.h"
 
@@ -469,6 +471,9 @@ gru_stack_bf16_ls(const GruBf16Params p) {
     float* biasl = reinterpret_cast<float*>(wc1 + 4 * 2 * 8 * 64); // [NL][3][128]
     EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + NL * 3 * H));
     if constexpr (WINDOW) epi.cwords = reinterpret_cast<int8_t*>(reinterpret_cast<char*>(biasl + NL * 3 * H) + kEpilogueLdsBytes);
+    const uint8_t* win_dl = reinterpret_cast<const uint8_t*>(epi.cwords) + 16 * kWinTailWordsStride;     // WINDOW only: the label matcher
+    constexpr size_t kWinOffset = offsetof(GruBf16Params, epi) + offsetof(GruLayerParams, win);
+    if constexpr (WINDOW) window_tail_prepare(window_tail_params_from_kernarg(kWinOffset), const_cast<uint8_t*>(win_dl), tid);   // (visible after the first barrier below)
 
     constexpr int KC0 = KX0 + 4, KC1 = 8;
     // ---- LDS init (all eight waves): biases, zeroed mel staging, layer 1's candidate operands, initial state -------
@@ -508,7 +513,10 @@ gru_stack_bf16_ls(const GruBf16Params p) {
         if constexpr (WINDOW) {
             // detector.py:195-209 for this group's 16 streams (all eight waves keep the barriers, four work): the call's
             // frame words wait in epi.cwords, the scratch is hb | rhb
-            window_tail(p.epi.win, p.B, group * kStreamsPerGroup, T, epi.cwords, reinterpret_cast<char*>(hb), tid);
+            const WindowTail win = window_tail_params_from_kernarg(kWinOffset);
+            WindowTailRegs<2> wreq;
+            window_tail_request<2>(win, p.B, group * kStreamsPerGroup, tid, wreq);
+            window_tail<2>(win, p.B, group * kStreamsPerGroup, T, epi.cwords, kWinTailWordsStride, win_dl, reinterpret_cast<char*>(hb), tid, wreq);
             __syncthreads();
         }
     };

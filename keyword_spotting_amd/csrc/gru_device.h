@@ -115,7 +115,7 @@ struct EpilogueLds {
     float* lring;
     int* words;
     int* carry;
-    int8_t* cwords;     // kernels instantiated with the window tail: [kWinTailMaxFrames][16] frame words of the whole call; else nullptr
+    int8_t* cwords;     // kernels instantiated with the window tail: [16 streams][kWinTailWordsStride] frame words of the whole call; else nullptr
 };
 constexpr size_t kEpilogueLdsBytes = (4 * 16 * 8 + kRingFrames * 16 * 8) * 4 + kRingFrames * 16 * 4 + 2 * 16 * 4;
 __device__ __forceinline__ EpilogueLds epilogue_carve(char* base) {
@@ -199,7 +199,15 @@ __device__ __forceinline__ void epilogue_flush(const GruLayerParams& p, const Ep
     }
     if (!(best > p.decode_thres)) word = -1;
     e.words[f * 16 + s] = word;
-    if (e.cwords != nullptr && f < n) e.cwords[(t0 + f) * 16 + s] = (int8_t)word;      // the call's words wait for the window tail
+    if (e.cwords != nullptr) {       // the call's words wait for the window tail
+        // the lane's row offset is recomputed HERE from an opaque copy of `lane`: hoisted out of the frame loop it is one more
+        // live register there, gets spilled in the register-resident kernels, and its reload (scratch_load + vmcnt(0)) makes every
+        // flush wait for all the stores and prefetches in flight
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int f2 = 4 * w + (ln & 3);
+        if (f2 < n) e.cwords[(ln >> 2) * kWinTailWordsStride + t0 + f2] = (int8_t)word;
+    }
     const bool mine = b < p.B && f < n;
     const size_t row = (size_t)b * (p.t_stride ? p.t_stride : p.T) + (t0 + f);
     if (mine) {

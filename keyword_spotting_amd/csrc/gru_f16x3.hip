@@ -39,6 +39,7 @@
 // allocates registers, inserts the waitcnts and sees every hazard (builtin MFMAs only: with MFMA results in VGPRs --
 // csrc/Makefile builds this file with -amdgpu-mfma-vgpr-form, as gru_bf16.hip -- hipcc feeds operands pinned into AGPRs
 // ("+a" at load time) to the builtin directly, no v_accvgpr_read copies; checked in the ISA).
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 
@@ -174,6 +175,9 @@ gru_layer_f16x3(const GruF16Params p) {
     float* biasl = reinterpret_cast<float*>(wul + 4 * NG * 4 * 64);    // [3][128] + [16] class bias
     EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * H + 16));      // LAST only
     if constexpr (WINDOW) epi.cwords = reinterpret_cast<int8_t*>(reinterpret_cast<char*>(biasl + 3 * H + 16) + kEpilogueLdsBytes);
+    const uint8_t* win_dl = reinterpret_cast<const uint8_t*>(epi.cwords) + 16 * kWinTailWordsStride;     // WINDOW only: the label matcher
+    constexpr size_t kWinOffset = offsetof(GruF16Params, epi) + offsetof(GruLayerParams, win);
+    if constexpr (WINDOW) window_tail_prepare(window_tail_params_from_kernarg(kWinOffset), const_cast<uint8_t*>(win_dl), tid);   // (visible after the group loop's first barrier)
 
     // ---- operands: [tile j][gate q][chunk][hi|lo]; table p.w is [8 tiles][3][KC][2][64 lanes] x 16 B, x chunks first ----
     const u32x4* wt_tab = reinterpret_cast<const u32x4*>(p.w);
@@ -678,7 +682,10 @@ gru_layer_f16x3(const GruF16Params p) {
             // detector.py:195-209 for this group's 16 streams: the call's frame words wait in epi.cwords (final flush), the
             // scratch is hb | rhb, which nobody reads after the last frame
             __syncthreads();
-            window_tail(p.epi.win, p.B, group * kStreamsPerGroup, T, epi.cwords, reinterpret_cast<char*>(hb), tid);
+            const WindowTail win = window_tail_params_from_kernarg(kWinOffset);
+            WindowTailRegs<2> wreq;
+            window_tail_request<2>(win, p.B, group * kStreamsPerGroup, tid, wreq);
+            window_tail<2>(win, p.B, group * kStreamsPerGroup, T, epi.cwords, kWinTailWordsStride, win_dl, reinterpret_cast<char*>(hb), tid, wreq);
             __syncthreads();
         }
     }

@@ -18,6 +18,8 @@
 //     mel / previous layer's h stream is read per step.
 //   * x-part MFMAs of frame t+1 are issued behind frame t's two barriers (software pipeline), so
 //     the LDS exchange latency overlaps independent matrix work.
+#include <cstddef>
+
 #include "gru_device.h"
 #include "window_device.h"
 
@@ -53,6 +55,9 @@ gru_layer_resident(const GruLayerParams p) {
     f32x4* wlds = rhbuf + NT * 64;                       // [4 waves][KCX][64] gate x-part: {r0,u0,r1,u1}
     EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(wlds + 4 * KCX * 64));   // LAST only
     if constexpr (WINDOW) epi.cwords = reinterpret_cast<int8_t*>(reinterpret_cast<char*>(wlds + 4 * KCX * 64) + kEpilogueLdsBytes);
+    const uint8_t* win_dl = reinterpret_cast<const uint8_t*>(epi.cwords) + 16 * kWinTailWordsStride;     // WINDOW only: the label matcher
+    constexpr size_t kWinOffset = offsetof(GruLayerParams, win);
+    if constexpr (WINDOW) window_tail_prepare(window_tail_params_from_kernarg(kWinOffset), const_cast<uint8_t*>(win_dl), tid);   // (visible after the group loop's first barrier)
     // FIRST only: one frame of mel for the group, [16 streams x 4 lane groups][kXsStride] floats, row
     // (4s+g) holds x[s][4*kc+g] for kc = 0..KCX-1 -- each lane's B operands are contiguous
     constexpr int kXsStride = xs_stride(KCX);       // 4 * odd: rows 16 apart in one ds_read_b128 group spread over the banks
@@ -435,7 +440,10 @@ gru_layer_resident(const GruLayerParams p) {
     __syncthreads();             // every wave is done with this group's LDS state before the next group overwrites it
     if constexpr (WINDOW) {
         // detector.py:195-209 for this group's 16 streams: the call's frame words wait in epi.cwords, the scratch is hbuf | rhbuf
-        window_tail(p.win, p.B, group * kStreamsPerGroup, T, epi.cwords, reinterpret_cast<char*>(hbuf), tid);
+        const WindowTail win = window_tail_params_from_kernarg(kWinOffset);
+        WindowTailRegs<2> wreq;
+        window_tail_request<2>(win, p.B, group * kStreamsPerGroup, tid, wreq);
+        window_tail<2>(win, p.B, group * kStreamsPerGroup, T, epi.cwords, kWinTailWordsStride, win_dl, reinterpret_cast<char*>(hbuf), tid, wreq);
         __syncthreads();
     }
     }

@@ -168,7 +168,7 @@ struct kws_window {
     int *lens = nullptr, *head = nullptr, *count = nullptr;
     // the incremental form (kws_window_step_incremental, kws_stream_feed): a summary per queued chunk instead of its frames
     // (window_device.h); a state of its own -- a window is driven through one of the two entry points, not both
-    uint8_t* inc_tab = nullptr;      // [B][nq][16]
+    uint8_t* inc_tab = nullptr;      // [B][nq][32]  tab | ftab
     uint32_t* inc_meta = nullptr;    // [B][nq]
     int *inc_head = nullptr, *inc_count = nullptr;
     uint8_t* inc_delta_dev = nullptr;   // [256] label matcher of the bound label
@@ -966,7 +966,13 @@ static int step_overlapped(kws_handle h, const float* mel, const float* state_in
 // 4-wave bf16 -- are followed by window_inc_kernel instead.)
 static bool step_takes_window(kws_handle h, int B, int T, int window_chunks) {
     const kws_config& c = h->cfg;
-    if (T < 1 || T > kws::kWinTailMaxFrames || window_chunks > kws::kWinTailMaxChunks) return false;
+    static const bool off = [] { const char* e = getenv("KWS_NO_WINDOW_TAIL"); return e && e[0] == '1'; }();     // A/B switch (tools/bench_e2e.py)
+    if (off || T < 1 || T > kws::kWinTailMaxFrames || window_chunks > kws::kWinTailMaxChunks) return false;
+    // One group per workgroup only: the tail is ~2 us of latency-bound work at the end of a group.  At the end of the launch
+    // that replaces a ~4 us launch of its own; in a persistent workgroup it would sit between two groups, on the critical
+    // path once per group (measured, bf16, 16384 streams: 0.349-0.359 ms per chunk with the tail against 0.338-0.340 with
+    // window_inc_kernel behind the stack)
+    if ((B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup > (h->num_cus > 0 ? h->num_cus : 256)) return false;
     if (c.precision == KWS_BF16) return kws::gru_stack_bf16_takes_window(h->bf_kx0, c.num_layers);
     if (c.precision == KWS_F16X3) return true;
     if (c.precision != KWS_FP32 || pipeline_eligible(h, B) || overlap_eligible(h, B, T)) return false;
@@ -1260,12 +1266,12 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres,
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->lens), (size_t)B * max_chunks * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->head), (size_t)B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->count), (size_t)B * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_tab), (size_t)B * max_chunks * 16);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_tab), (size_t)B * max_chunks * 32);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_meta), (size_t)B * max_chunks * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_head), (size_t)B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_count), (size_t)B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_delta_dev), 256);
-    if (e == hipSuccess) e = hipMemset(wnd->inc_tab, 0, (size_t)B * max_chunks * 16);
+    if (e == hipSuccess) e = hipMemset(wnd->inc_tab, 0, (size_t)B * max_chunks * 32);
     if (e == hipSuccess) e = hipMemset(wnd->inc_meta, 0, (size_t)B * max_chunks * sizeof(uint32_t));
     if (e == hipSuccess) e = kws::launch_window_reset(B, wnd->inc_head, wnd->inc_count, nullptr);
     if (e == hipSuccess) e = kws::launch_window_reset(B, wnd->head, wnd->count, nullptr);
@@ -1336,7 +1342,8 @@ static void window_label_delta(const char* label, int n, uint8_t* delta) {
 // matcher (synchronises); the same label again is free; another label while chunks may be queued is refused.
 static int window_bind_label(kws_window* w, const char* label) {
     const int n = (int)strlen(label);
-    if (n > 16) return fail(KWS_ERR_INVALID_ARGUMENT, "label longer than 16 digits");
+    if (n > 15) return fail(KWS_ERR_INVALID_ARGUMENT, "the incremental window takes labels of up to 15 digits (its matcher has 16 states); "
+                            "kws_window_step re-scans the frames for longer ones");
     for (int i = 0; i < n; ++i)
         if (label[i] < '1' || label[i] > '9') return fail(KWS_ERR_INVALID_ARGUMENT, "label must be digits 1..9, got '%s'", label);
     if (w->inc_bound) {

@@ -42,7 +42,8 @@ inline hipError_t grant_dynamic_lds(K kernel, LdsGrant& cache, size_t lds) {
 // The incremental decode window of a stream manager (window_device.h), run as the tail of the last layer's launch or by
 // window_inc_kernel.  tab == nullptr: none.
 struct WindowTail {
-    uint8_t* tab;               // [B][nq][16]  per queued chunk: matcher state after its frames 1..n-1 when entered in state q
+    uint8_t* tab;               // [B][nq][32]  per queued chunk: tab[16] matcher state after its frames 1..n-1 when entered in state q; ftab[16] the same
+                                //              with its first frame decided against its predecessor's last word (window_device.h)
     uint32_t* meta;             // [B][nq]      bit 16: the chunk has frames; bits 0-7: first frame's word + 1; bits 8-15: last frame's word + 1
     int* head;                  // [B]
     int* count;                 // [B]
@@ -53,9 +54,10 @@ struct WindowTail {
     int nq, n_label;
 };
 constexpr int kWinTailMaxFrames = 64;   // chunk lengths the fused tail takes (its per-frame words wait in LDS): longer -> window_inc_kernel
-constexpr int kWinTailMaxChunks = 32;   // window lengths the fused tail takes (the rings of 16 streams are staged in LDS)
-constexpr size_t kWinTailWordsBytes = (size_t)kWinTailMaxFrames * 16;
-__host__ __device__ inline size_t window_tail_scratch_bytes(int nq) { return 512 + (size_t)16 * nq * 20; }
+constexpr int kWinTailMaxChunks = 24;   // window lengths the fused tail takes (the rings of 16 streams are staged in 16 KiB of LDS)
+constexpr int kWinTailWordsStride = kWinTailMaxFrames + 4;                    // bytes per stream row of the words (68: rows on different banks)
+constexpr size_t kWinTailWordsBytes = (size_t)16 * kWinTailWordsStride + 256;   // the call's words [16 streams][stride] + the label matcher [16][16]
+__host__ __device__ inline size_t window_tail_scratch_bytes(int nq) { return (size_t)16 * (nq * 32 + 32); }
 
 struct GruLayerParams {
     // weights (device, packed by pack.cpp)

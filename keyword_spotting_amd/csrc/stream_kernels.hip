@@ -108,11 +108,14 @@ __global__ void __launch_bounds__(64) window_step_kernel(const WindowParams p) {
 // over the chunk's softmax rows, then window_tail.
 __global__ void __launch_bounds__(256) window_inc_kernel(const WindowIncParams p) {
     extern __shared__ __attribute__((aligned(16))) char wlds[];
-    int8_t* cw = reinterpret_cast<int8_t*>(wlds);                              // [T][16]
-    char* scratch = wlds + (((size_t)p.T * 16 + 15) & ~(size_t)15);
-    uint8_t* dsrc = reinterpret_cast<uint8_t*>(scratch) + window_tail_scratch_bytes(p.win.nq);   // the by-value table, where the tail can load it from
+    const int stride = (p.T + 15) & ~15;
+    int8_t* cw = reinterpret_cast<int8_t*>(wlds);                              // [16 streams][stride]
+    uint8_t* dl = reinterpret_cast<uint8_t*>(wlds) + (size_t)16 * (stride > 0 ? stride : 16);
+    char* scratch = reinterpret_cast<char*>(dl) + 256;
     const int tid = threadIdx.x, b0 = blockIdx.x * 16, C = p.C;
-    dsrc[tid] = p.delta[tid];
+    dl[tid] = p.delta[tid];
+    WindowTailRegs<4> req;
+    window_tail_request<4>(p.win, p.B, b0, tid, req);       // in flight behind the frame rule below
     const int s = tid & 15, b = min(b0 + s, p.B - 1);
     for (int t = tid >> 4; t < p.T; t += 16) {
         const float* row = p.softmax + ((size_t)b * p.T + t) * C;
@@ -120,12 +123,10 @@ __global__ void __launch_bounds__(256) window_inc_kernel(const WindowIncParams p
         int arg = 0;
         for (int c = 2; c < C - 1; ++c)
             if (row[c] > best) { best = row[c]; arg = c - 1; }
-        cw[t * 16 + s] = (int8_t)(best > p.thres ? arg : -1);
+        cw[s * stride + t] = (int8_t)(best > p.thres ? arg : -1);
     }
     __syncthreads();
-    WindowTail W = p.win;
-    W.delta = dsrc;                 // LDS address through the generic pointer
-    window_tail(W, p.B, b0, p.T, cw, scratch, tid);
+    window_tail<4>(p.win, p.B, b0, p.T, cw, stride, dl, scratch, tid, req);
 }
 
 __global__ void window_reset_kernel(int B, int* head, int* count) {
@@ -138,7 +139,8 @@ hipError_t launch_window_step(const WindowParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t launch_window_inc(const WindowIncParams& p, hipStream_t st) {
-    const size_t lds = (((size_t)p.T * 16 + 15) & ~(size_t)15) + window_tail_scratch_bytes(p.win.nq) + 256;
+    const int stride = (p.T + 15) & ~15;
+    const size_t lds = (size_t)16 * (stride > 0 ? stride : 16) + 256 + window_tail_scratch_bytes(p.win.nq);
     static LdsGrant granted;
     if (lds > 48 * 1024) {
         const hipError_t e = grant_dynamic_lds(window_inc_kernel, granted, lds);

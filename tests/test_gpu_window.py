@@ -51,8 +51,8 @@ class DeviceWindow(object):
         self.lib.kws_window_destroy(self.h)
 
 
-@pytest.mark.parametrize("nq,tmax,label", [(15, 23, "1233"), (1, 9, "3"), (2, 40, "12"), (3, 23, "121"), (17, 5, "33"), (32, 16, "1212"),
-                                           (64, 7, "2312"), (15, 23, "1234123412341234")])
+@pytest.mark.parametrize("nq,tmax,label", [(15, 23, "1233"), (1, 9, "3"), (2, 40, "12"), (3, 23, "121"), (17, 5, "33"), (24, 16, "1212"), (32, 16, "1212"),
+                                           (64, 7, "2312"), (15, 23, "123412341234123")])
 def test_incremental_kernel_equals_the_rescan_kernel_the_model_and_the_oracle(nq, tmax, label):
     """Random word plateaus over many chunks of ragged length (0 frames included), per stream: windows fill, evict with a word
     held across the evicted chunk, clear on silence and restart on hits.  Four implementations must agree on every chunk."""
@@ -145,6 +145,8 @@ def test_the_label_is_bound_to_the_incremental_state():
         win.step(sm, np.zeros(4, np.uint8), "13")           # the queued summaries were built for '12'
     with pytest.raises(_lib.InvalidArgumentError):
         win.step(sm, np.zeros(4, np.uint8), "1x")
+    with pytest.raises(_lib.InvalidArgumentError):
+        DeviceWindow(4, 15, 8, True).step(sm, np.zeros(4, np.uint8), "1234123412341234")      # 16 digits: the matcher has 16 states
     assert win.step(sm, np.zeros(4, np.uint8), "12").tolist() == [0, 0, 0, 0]
     win.close()
     empty = DeviceWindow(2, 3, 4, True)
@@ -221,17 +223,16 @@ def test_stream_feed_carries_the_window_in_the_last_layer_launch(precision, kern
         mm.close()
 
 
-def test_fused_window_with_more_stream_groups_than_cus_and_a_long_window():
-    """Persistent workgroups (B > 16 x CUs: every workgroup runs the tail once per group it takes) and a 32-chunk window, the
-    largest the fused tail stages; 33 chunks fall back to window_inc_kernel.  Decisions equal the mel-fed manager's, which
-    steps the window as a launch of its own."""
+def test_where_the_window_rides_and_where_it_follows():
+    """The tail rides in the last layer's launch when every workgroup takes ONE group of streams and the window is at most 24
+    chunks (what it stages in LDS); persistent workgroups (B > 16 x CUs) and longer windows are followed by window_inc_kernel
+    instead.  Decisions equal the mel-fed manager's either way, ragged last group included."""
     from keyword_spotting_amd import get_config
     from keyword_spotting_amd.detector import StreamManager
     from keyword_spotting_amd.frontend import MelFrontend
     from keyword_spotting_amd.rnn_ctc import DeployModel
     cfg = get_config(precision="bf16")
     w = _keyword_weights(seed=9)
-    b = 16 * 300 + 5
     rng = np.random.default_rng(7300)
     fe = MelFrontend(cfg)
     probe = DeployModel(cfg, w)
@@ -241,7 +242,8 @@ def test_fused_window_with_more_stream_groups_than_cus_and_a_long_window():
     words = np.concatenate([D.ctc_decode2(sm[k], 6)[1::2] for k in range(64)])
     assert words.size > 0
     label = str(int(np.bincount(words).argmax()))
-    for nq, fused in ((32, True), (33, False)):
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for b, nq, fused in ((16 * (cus + 40) + 5, 15, False), (16 * (cus - 50) + 5, 24, True), (16 * (cus - 50) + 5, 25, False)):
         ma, mb = DeployModel(cfg, w), DeployModel(cfg, w)
         a = StreamManager(ma, batch=b, label=label, window_chunks=nq)
         ref = StreamManager(mb, batch=b, label=label, window_chunks=nq)
@@ -250,12 +252,12 @@ def test_fused_window_with_more_stream_groups_than_cus_and_a_long_window():
         for ci in range(6):
             x = torch.from_numpy((rng.standard_normal((b, 3600)) * 0.2).astype(np.float32)).cuda()
             got = a.feed_pcm(x, fe).cpu().numpy()
-            assert any("window tail" in nm for nm in ma.kernel_names()) == fused
+            assert any("window tail" in nm for nm in ma.kernel_names()) == fused, (b, nq)
             data = torch.cat([carry, x], 1)
             keep = (data.shape[1] - 400) % 160 + 240
             carry = data[:, data.shape[1] - keep:].contiguous()
             want = ref.feed(fe.forward(data.contiguous()), pcm_chunk=x).cpu().numpy()
-            np.testing.assert_array_equal(got, want, err_msg="nq %d chunk %d" % (nq, ci))
+            np.testing.assert_array_equal(got, want, err_msg="b %d nq %d chunk %d" % (b, nq, ci))
             total += int(want.sum())
         assert total > 0
         a.close(); ref.close(); ma.close(); mb.close()

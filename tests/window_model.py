@@ -49,36 +49,54 @@ def summarise(words, delta, n_label):
 
 
 class IncrementalWindow(object):
+    """The summary ring exactly as csrc/window_device.h keeps it.  Besides tab (the chunk as the OLDEST of the window: its first
+    frame is decided at evaluation time) every slot carries ftab: the chunk's whole table with its first frame already decided
+    against the last word of its predecessor -- the nearest earlier non-empty chunk at the time it was queued.  Evictions are
+    FIFO, so that predecessor is either still queued (ftab is right) or gone together with everything before it (the chunk
+    is then the first non-empty one and is evaluated through tab).  Evaluation = one table lookup per queued chunk."""
+
     def __init__(self, max_chunks, label_digits):
         self.nq, self.label = int(max_chunks), list(label_digits)
         self.delta = kmp_delta(self.label)
-        self.ring = []                       # summaries, oldest first
+        self.ring = []                       # (n, first, last, tab, ftab), oldest first
 
     def step(self, words, clear_before=False):
         """One chunk: [clear]; add; evaluate; on a hit clear.  -> 1 / 0."""
         n_label = len(self.label)
         if clear_before:
             self.ring = []
+        pred = [e for e in self.ring if e[0] > 0]
+        pred_last = pred[-1][2] if pred else -1               # (may be the chunk evicted right below: ftab is then never used)
         if len(self.ring) == self.nq:
             self.ring.pop(0)
-        self.ring.append(summarise(list(words), self.delta, n_label))
+        n, first, last, tab = summarise(list(words), self.delta, n_label)
+        states = max(n_label, 1)
+        if n == 0:
+            ftab = list(range(states))
+        elif first >= 0 and first != pred_last:
+            ftab = [tab[self.delta[q][first + 1]] if self.delta[q][first + 1] < n_label else n_label for q in range(states)]
+        else:
+            ftab = list(tab)
+        self.ring.append((n, first, last, tab, ftab))
         if n_label == 0:
             hit = True                        # '' is a substring of anything (utils/prediction.py:118)
         else:
-            q, prev_last, hit = 0, -1, False
-            for n, first, last, tab in self.ring:
+            q, seen = 0, False
+            for n, first, last, tab, ftab in self.ring:
+                if q == n_label:
+                    break                     # absorbing
                 if n == 0:
                     continue
-                if first >= 0 and first != prev_last:
-                    q = self.delta[q][first + 1]
-                    if q == n_label:
-                        hit = True
-                        break
-                q = tab[q]
-                if q == n_label:
-                    hit = True
-                    break
-                prev_last = last
+                if not seen:                  # the first non-empty chunk: nothing before it in the window
+                    seen = True
+                    if first >= 0:
+                        q = self.delta[q][first + 1]
+                        if q == n_label:
+                            break
+                    q = tab[q]
+                else:
+                    q = ftab[q]
+            hit = q == n_label
         if hit:
             self.ring = []
         return int(hit)
