@@ -156,9 +156,15 @@ __device__ __forceinline__ void epilogue_fold_store(const EpilogueLds& e, int t,
     }
 }
 
-// flush frames [t0, t0+n) of the ring; called by all four waves of the group together
+// flush frames [t0, t0+n) of the ring; called by all four waves of the group together.
+// OPAQUE_LANE: everything the flush derives from the lane index (row pointers, LDS addresses) is computed HERE from an opaque
+// copy of it.  Otherwise the compiler hoists those per-lane values out of the frame loop; in gru_layer_f16x3's last-layer
+// kernels, which have no register to spare, they get spilled, and every reload (scratch_load + s_waitcnt vmcnt(0)) makes the
+// flush wait for the acknowledgement of the stores it has just issued -- several microseconds per call at T = 22.
+template <bool OPAQUE_LANE = false>
 __device__ __forceinline__ void epilogue_flush(const GruLayerParams& p, const EpilogueLds& e, int group, int t0,
                                                int n, int w, int lane, bool final_flush) {
+    if constexpr (OPAQUE_LANE) asm volatile("" : "+v"(lane));
     const int f = 4 * w + (lane & 3);          // frame within the block
     const int s = lane >> 2;
     const int b = group * kStreamsPerGroup + s;
@@ -199,10 +205,7 @@ __device__ __forceinline__ void epilogue_flush(const GruLayerParams& p, const Ep
     }
     if (!(best > p.decode_thres)) word = -1;
     e.words[f * 16 + s] = word;
-    if (e.cwords != nullptr) {       // the call's words wait for the window tail
-        // the lane's row offset is recomputed HERE from an opaque copy of `lane`: hoisted out of the frame loop it is one more
-        // live register there, gets spilled in the register-resident kernels, and its reload (scratch_load + vmcnt(0)) makes every
-        // flush wait for all the stores and prefetches in flight
+    if (e.cwords != nullptr) {       // the call's words wait for the window tail (row offset from an opaque copy of the lane, as above)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int f2 = 4 * w + (ln & 3);

@@ -559,7 +559,7 @@ gru_layer_f16x3(const GruF16Params p) {
 #ifndef KWS_ABL_NOFLUSH      // experiment builds only (tools/build_variant.sh): what the periodic flush costs
                 if (t > 0 && (t & (kRingFrames - 1)) == 0) {
                     lds_barrier();
-                    epilogue_flush(p.epi, epi, group, t - kRingFrames, kRingFrames, w, lane, false);
+                    epilogue_flush<true>(p.epi, epi, group, t - kRingFrames, kRingFrames, w, lane, false);
                 }
 #endif
             }
@@ -660,7 +660,7 @@ gru_layer_f16x3(const GruF16Params p) {
                     for (int k = 1; k < 4; ++k) v += *reinterpret_cast<const f32x4*>(epi.pstage + (k * 16 + fs) * 8 + 4 * fh);
                     *reinterpret_cast<f32x4*>(epi.lring + (((t & (kRingFrames - 1)) * 16 + fs) * 8 + 4 * fh)) = v;
                     lds_barrier();
-                    epilogue_flush(p.epi, epi, group, t0, t - t0 + 1, w, lane, true);
+                    epilogue_flush<true>(p.epi, epi, group, t0, t - t0 + 1, w, lane, true);
                 }
             }
             KWS_STAMP(9);
