@@ -349,7 +349,11 @@ __global__ void __launch_bounds__(256, KWS_FE_OCC) mel_fft400_kernel(const Front
 
     // ---- mel projection: wave m = mel tile m over its contiguous run of 4-bin groups.  A = basis fragments
     // [tile][group][64 lanes], B = four spectrum rows (k = g) x 16 frames; two accumulators break the dependent chain ----
+#ifdef KWS_ABL_NOMEL          // experiment builds only (tools/build_variant.sh nomel -DKWS_ABL_NOMEL): the kernel without its mel projection
+    if (n > 0 && p.n_mel < 0) {
+#else
     if (n > 0) {
+#endif
         const float* Sg = S + lo4 * 64 + lane;
         f32x4 acc0 = splat4(0.f), acc1 = splat4(0.f);
         // runs are padded to multiples of four groups: four spectrum reads in flight, then four MFMAs
