@@ -280,7 +280,7 @@ def secondary_lines(device):
             kb[0] += 1
         for _ in range(3):
             chunk_big()
-        dt = timed(chunk_big, 10)
+        dt = timed(chunk_big, 60)
         out["detector.py loop, PCM in -> trigger out, %s, %d streams x 225 ms chunks per call" % (prec, big)] = {
             "realtime_streams": big * 0.225 / dt, "ms_per_chunk": dt * 1e3}
         mgr.close()
@@ -298,11 +298,16 @@ def secondary_lines(device):
             chunk()
         m.set_profiling(True)
         m.kernel_times()
-        dt = timed(chunk, 20)
+        dt = timed(chunk, 200)
         kt = m.kernel_times()
         m.set_profiling(False)
         frames = B * 22.5                                   # 3600-sample hops: 22 and 23 frames alternate
-        entry = {"realtime_streams": B * 0.225 / dt, "ms_per_chunk": dt * 1e3}
+        names = m.kernel_names()
+        rides = any("window tail" in nm for nm in names)
+        gru_launches = sum(1 for nm in names if nm)
+        entry = {"realtime_streams": B * 0.225 / dt, "ms_per_chunk": dt * 1e3,
+                 "kernel_launches_per_chunk": 1 + gru_launches + (0 if rides else 1),
+                 "window_step": ("incremental, inside the last GRU layer's launch" if rides else "incremental, window_inc_kernel behind the stack")}
         if prec == "fp32":
             per = [k_[0] / max(k_[1], 1) for k_ in kt]
             entry["gru_kernels"] = [{"kernel": "gru_layer_resident layer %d" % l, "kernel_ms": per[l],
