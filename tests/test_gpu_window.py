@@ -90,6 +90,33 @@ def test_incremental_kernel_equals_the_rescan_kernel_the_model_and_the_oracle(nq
     ref.close()
 
 
+def test_incremental_kernel_property_against_the_rescan_oracle():
+    """hypothesis drives the DEVICE kernel: arbitrary chunk lists (empty chunks, held words straddling chunk and eviction
+    boundaries, clears), small and reference-sized windows, several labels -- every decision equals the oracle's
+    SimpleQueue + concatenate + ctc_decode2 + ctc_predict replay (the same strategies as tests/test_window_incremental.py)."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    from tests.test_window_incremental import RescanWindow
+    chunk = st.lists(st.integers(-1, 3), min_size=0, max_size=7)
+    held = st.builds(lambda w, n, tail: [w] * n + tail, st.integers(-1, 3), st.integers(0, 6), st.lists(st.integers(-1, 3), max_size=2))
+
+    @settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+    @given(chunks=st.lists(st.tuples(st.one_of(chunk, held), st.booleans()), min_size=1, max_size=30),
+           nq=st.sampled_from([1, 2, 3, 4, 15]), label=st.sampled_from(["1233", "12", "1", "11", "121", "33", "1212"]))
+    def run(chunks, nq, label):
+        win, ref = DeviceWindow(3, nq, 9, True), RescanWindow(nq, label)
+        try:
+            for k, (words, flag) in enumerate(chunks):
+                clear = bool(flag and k % 3 == 0)
+                w = np.asarray(words, np.int64).reshape(1, -1)
+                got = win.step(rows_for(np.repeat(w, 3, 0)), [clear] * 3, label)
+                want = ref.step(words, clear)
+                assert (got == want).all(), (k, words, clear, nq, label, got, want)
+        finally:
+            win.close()
+    run()
+
+
 def test_incremental_kernel_on_the_reference_generated_traces():
     g = np.load(GOLDEN)
     hits = 0
