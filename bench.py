@@ -314,7 +314,8 @@ def secondary_lines(device):
                                      "tflops": FLOP_PER_FRAME["layer"][l] * frames / (per[l] * 1e-3) / 1e12,
                                      "frac": FLOP_PER_FRAME["layer"][l] * frames / (per[l] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
                                     for l in range(len(per))]
-            for l, pat in enumerate(("gru_layer_resident<10, true, false>", "gru_layer_resident<32, false, true>")):
+            # (rocprof names carry the kernels' fourth template parameter: the loop's last layer is the instantiation with the window tail)
+            for l, pat in enumerate(("gru_layer_resident<10, true, false, false>", "gru_layer_resident<32, false, true, %s>" % ("true" if rides else "false"))):
                 rp, rp_src = rocprof_kernel_avg_ms(pat, "e2e")           # the committed trace of tools/bench_e2e.py (same loop)
                 if rp:
                     entry["gru_kernels"][l].update({"kernel_ms_rocprof": rp, "rocprof_source": rp_src,
@@ -658,7 +659,7 @@ def main(argv=None, model_factory=None):
             # (3 instructions per 2 pairs = 8 int ops / 3 lane-instructions)
             peak, bound = 256 * 64 * 2.4e9 * (8.0 / 3.0) / 1e12, "valu-pk-i16 (secondary line)"
         all_ms = sum(k[0] / max(k[1], 1) for k in ktimes)
-        dom_name = "gru_layer_resident<%s>" % ("10, true, false" if dom == 0 else "32, false, true")
+        dom_name = "gru_layer_resident<%s, false>" % ("10, true, false" if dom == 0 else "32, false, true")   # as rocprofv3 prints it (4th parameter: no window tail)
         pmc, traffic_src = pmc_traffic_all() if getattr(model, "kernel", "") != "generic" and args.precision == "fp32" else ({}, None)
         traffic = next((v for k, v in pmc.items() if dom_name in k), None)
         pmc_step = sum(v for k, v in pmc.items() if "gru_layer_resident" in k) if pmc else None
