@@ -6,7 +6,7 @@ from keyword_spotting_amd import get_config, weights
 from keyword_spotting_amd.rnn_ctc import DeployModel
 cfg = get_config(precision="f16x3")
 m = DeployModel(cfg, weights.init_weights(cfg, seed=0))
-B, T = 4096, 300
+B, T = 4096, int(os.environ.get("KWS_T", "300"))
 mel = (torch.randn(B, T, cfg.n_mel, device="cuda").abs() * 2).contiguous()
 st = m.zero_state(B)
 for _ in range(2):
