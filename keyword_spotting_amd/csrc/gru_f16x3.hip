@@ -157,9 +157,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 gru_layer_f16x3(const GruF16Params p) {
     static_assert(!WINDOW || LAST, "the window tail belongs to the last layer");
     constexpr int H = 128, KC = KX + 4;
-#ifdef KWS_F16_TIMING
-    const long long t_entry = __builtin_readcyclecounter();
-#endif
     constexpr int NG = lds_groups<KX, FIRST>();          // LDS-resident operand groups per wave (0 or 7)
     constexpr int NX = 18 * KX;                          // MFMAs of one frame's x-part
     static_assert(FIRST ? NG == 0 : NG == 7, "gru_f16x3_lds_bytes assumes 7 streamed groups above the first layer");
@@ -303,10 +300,6 @@ gru_layer_f16x3(const GruF16Params p) {
     asm volatile("" : "+s"(cLoInv), "+s"(cLoScale), "+s"(cNegLoScale), "+s"(cNegTwo));
 
     for (int group = blockIdx.x; group < n_groups; group += gridDim.x) {
-#ifdef KWS_F16_TIMING
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        const long long t_group = __builtin_readcyclecounter();
-#endif
         const int b_raw = group * kStreamsPerGroup + s;
         const bool bvalid = b_raw < p.B;
         const int b = bvalid ? b_raw : p.B - 1;
@@ -530,8 +523,6 @@ gru_layer_f16x3(const GruF16Params p) {
 #ifdef KWS_F16_TIMING
         long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         long long tlast = __builtin_readcyclecounter();
-        tsum[12] = tlast - t_group;          // state, x(0), x(1), barriers, frame 0's x-part
-        tsum[11] = t_group - t_entry;        // (first group only meaningful) weight staging up to the group loop
 #endif
         int slot1 = 1 % NS, slot2 = 2 % NS;      // xsb slots of frames t+1 and t+2
 
@@ -679,7 +670,6 @@ gru_layer_f16x3(const GruF16Params p) {
             if (t + 1 < T) frame(std::integral_constant<int, 1>{}, t + 1);
         }
 #ifdef KWS_F16_TIMING
-        tsum[13] = __builtin_readcyclecounter() - tlast;      // after the last frame's stamp: final flush
         if (g_timing && lane == 0 && group < 4)
             for (int i = 0; i < 16; ++i) g_timing[((FIRST ? 0 : 16) + group * 4 + w) * 16 + i] = tsum[i];
 #endif
@@ -750,10 +740,7 @@ static hipError_t launch_f16x3m(const GruF16Params& p, hipStream_t st) {
         for (int i = 0; i < 10; ++i)
             fprintf(stderr, " %s=%lld/%lld/%lld/%lld", nm[i], h[(base + 0) * 16 + i] / p.T, h[(base + 1) * 16 + i] / p.T, h[(base + 2) * 16 + i] / p.T,
                     h[(base + 3) * 16 + i] / p.T);
-        fprintf(stderr, "\n   per call (group 0, waves 0..3): staging=%lld/%lld/%lld/%lld  group prologue=%lld/%lld/%lld/%lld  after last frame=%lld/%lld/%lld/%lld\n",
-                h[(base + 0) * 16 + 11], h[(base + 1) * 16 + 11], h[(base + 2) * 16 + 11], h[(base + 3) * 16 + 11],
-                h[(base + 0) * 16 + 12], h[(base + 1) * 16 + 12], h[(base + 2) * 16 + 12], h[(base + 3) * 16 + 12],
-                h[(base + 0) * 16 + 13], h[(base + 1) * 16 + 13], h[(base + 2) * 16 + 13], h[(base + 3) * 16 + 13]);
+        fprintf(stderr, "\n");
     }
 #endif
     return hipGetLastError();
