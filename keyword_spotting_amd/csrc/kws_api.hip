@@ -949,6 +949,7 @@ static int step_overlapped(kws_handle h, const float* mel, const float* state_in
             hipError_t e = resident ? kws::launch_gru_layer_resident(p, first, last, sx)
                                     : kws::launch_gru_layer_generic(p, H, first, last, sx);
             if (e != hipSuccess) return hip_fail(e, "launch (overlapped layers)");
+            if (k == 0) h->launch_tag[l] = {(uint8_t)(resident ? kws_model::kResident : kws_model::kGeneric), (uint8_t)(resident ? p.KCX : H / 64), first, last, 0};
             KWS_HIP(hipEventRecord(done(l, k), sx));
         }
     }

@@ -288,3 +288,56 @@ def test_where_the_window_rides_and_where_it_follows():
             total += int(want.sum())
         assert total > 0
         a.close(); ref.close(); ma.close(); mb.close()
+
+
+def _emitting_model(cfg, fe, b, rng, kernel="auto", layers=2):
+    """Random weights whose model really says something on noise (random weights never spell "1233"): the first seed that emits
+    at least two words per stream; -> (weights, its most frequent word as a one-digit label, the decoded sequences)."""
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    noise = torch.from_numpy((rng.standard_normal((b, 16000)) * 0.2).astype(np.float32))
+    for seed in range(7200, 7260):
+        w = G.random_weights(40, 128, layers, 6, seed=seed)
+        w["Wfc"] = (w["Wfc"] * 4.0).astype(np.float32)
+        probe = DeployModel(cfg, w, kernel=kernel)
+        sm = probe.forward(fe.forward(noise), probe.zero_state(b), want_logits=False)["softmax"].cpu().numpy()
+        probe.close()
+        seqs = [D.ctc_decode2(sm[k], 6)[1::2] for k in range(b)]
+        words = np.concatenate(seqs)
+        if words.size >= 2 * b:
+            return w, str(int(np.bincount(words).argmax())), seqs
+    raise AssertionError("no seed gives a model that emits words")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16"])
+def test_long_chunks_at_the_tails_frame_limit(precision):
+    """The fused tail keeps a call's frame words in LDS for up to 64 frames: chunks that give exactly 63 / 64 frames ride, 65 and
+    more are followed by window_inc_kernel; decisions equal the host mirror's either way (several 16-frame flush blocks per call)."""
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.detector import HotwordDetector, StreamManager
+    from keyword_spotting_amd.frontend import MelFrontend
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg = get_config(precision=precision)
+    fe = MelFrontend(cfg)
+    b = 19
+    rng = np.random.default_rng(7400)
+    w, label, _ = _emitting_model(cfg, fe, b, rng)
+    md, mm = DeployModel(cfg, w), DeployModel(cfg, w)
+    det = HotwordDetector(md, batch=b, label=label, window_chunks=5)
+    mgr = StreamManager(mm, batch=b, label=label, window_chunks=5, max_frames=80)
+    carry, seen, total = 0, set(), 0
+    for n in (400 + 160 * 62, 160 * 64 - 0, 160 * 63 + 7, 160 * 65, 160 * 64, 160 * 70, 3600, 160 * 63):
+        x = torch.from_numpy((rng.standard_normal((b, n)) * 0.2).astype(np.float32)).cuda()
+        want = np.zeros(b, np.int32)
+        want[det.feed_pcm(x, fe)] = 1
+        got = mgr.feed_pcm(x, fe).cpu().numpy()
+        frames = D.frames_in(carry + n)
+        carry = D.carry_len(carry + n)
+        np.testing.assert_array_equal(got, want, err_msg="%s chunk of %d samples (%d frames)" % (precision, n, frames))
+        assert torch.equal(mgr.state, det.state)
+        # (fp32 below half a chip of streams runs calls of >= 64 frames with its layers overlapped on HIP streams: no tail there)
+        rides = frames <= 64 and not (precision == "fp32" and frames >= 64)
+        assert any("window tail" in nm for nm in mm.kernel_names()) == rides, (frames, mm.kernel_names())
+        seen.add(frames)
+        total += int(want.sum())
+    assert {63, 64}.intersection(seen) and any(f > 64 for f in seen) and total > 0, (seen, total)
+    mgr.close(); md.close(); mm.close()
