@@ -48,9 +48,22 @@ torch.cuda.synchronize(); v2 = ev()
 for _ in range(20):
     _lib.check(mgr._lib.kws_window_step(mgr._win, _lib.ptr(sm), 22, _lib.ptr(silent), mgr.label, _lib.ptr(mgr.hit), _lib.ptr(mgr.restart), _lib.current_stream_ptr()))
 v3 = ev(); torch.cuda.synchronize()
-print("  alone: front-end without the gate %.3f ms, GRU stack %.3f ms (T=%d), window step %.3f ms; in the loop the gate and the next carry ride on"
-      " the front-end launch (rocprofv3 --kernel-trace --stats on this script gives the per-kernel split)" % (
-      s0.elapsed_time(s1) / 20, s1.elapsed_time(s2) / 20, mel.shape[1], v2.elapsed_time(v3) / 20))
+# ... and the incremental form on a window of its own (the loop above runs it inside the last GRU launch, or as window_inc_kernel behind it)
+import ctypes
+win2 = ctypes.c_void_p()
+_lib.check(mgr._lib.kws_window_create(a.batch, 15, 32, cfg.num_classes, 0.4, ctypes.byref(win2)))
+hit2 = torch.zeros(a.batch, dtype=torch.int32, device="cuda")
+for _ in range(16):
+    _lib.check(mgr._lib.kws_window_step_incremental(win2, _lib.ptr(sm), 22, _lib.ptr(silent), mgr.label, _lib.ptr(hit2), None, _lib.current_stream_ptr()))
+torch.cuda.synchronize(); v4 = ev()
+for _ in range(20):
+    _lib.check(mgr._lib.kws_window_step_incremental(win2, _lib.ptr(sm), 22, _lib.ptr(silent), mgr.label, _lib.ptr(hit2), None, _lib.current_stream_ptr()))
+v5 = ev(); torch.cuda.synchronize()
+mgr._lib.kws_window_destroy(win2)
+print("  alone: front-end without the gate %.3f ms, GRU stack %.3f ms (T=%d), window step as the reference's re-scan %.3f ms / incremental %.3f ms (full 15-chunk window;"
+      " host-paced); in the loop the gate and the next carry ride on the front-end launch, the window step on the last GRU launch"
+      " (rocprofv3 --kernel-trace --stats on this script gives the per-kernel split)" % (
+      s0.elapsed_time(s1) / 20, s1.elapsed_time(s2) / 20, mel.shape[1], v2.elapsed_time(v3) / 20, v4.elapsed_time(v5) / 20))
 print("B=%d precision=%s: %.3f ms per 225 ms chunk (wall %.3f) -> one GPU sustains %.0f real-time streams; "
       "front-end %.3f ms, GRU stack %.3f ms (T=%d)" % (a.batch, a.precision, e0.elapsed_time(e1) / a.chunks, wall * 1e3 / a.chunks,
       a.batch * 225.0 / (wall * 1e3 / a.chunks), s0.elapsed_time(s1) / 20, s1.elapsed_time(s2) / 20, mel.shape[1]))
