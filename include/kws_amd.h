@@ -253,7 +253,7 @@ int kws_window_step_incremental(kws_window_handle h, const float* softmax /*[B,T
  * fft_size samples in total so far: the reference still runs its whole iteration on such a chunk, and so does this --
  * the VAD decision clears state and window, every sample is carried, the model runs over zero frames (state handed
  * back, or zeroed where the VAD said silence) and the empty softmax takes a slot of the window before the windowed
- * decode.  `label`: digits '1'..'9'. */
+ * decode.  `label`: up to 15 digits '1'..'9' (the incremental window's matcher has 16 states). */
 typedef struct kws_stream* kws_stream_handle;
 int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window_handle window, int B, int max_chunk_samples,
                       float vad_thres, const char* label, float* state, uint8_t* restart, kws_stream_handle* out);
