@@ -175,6 +175,12 @@ def test_the_label_is_bound_to_the_incremental_state():
     with pytest.raises(_lib.InvalidArgumentError):
         DeviceWindow(4, 15, 8, True).step(sm, np.zeros(4, np.uint8), "1234123412341234")      # 16 digits: the matcher has 16 states
     assert win.step(sm, np.zeros(4, np.uint8), "12").tolist() == [0, 0, 0, 0]
+    # argument checks mirror kws_window_step's: T outside [0, max_frames], null pointers
+    lib = _lib.load()
+    assert lib.kws_window_step_incremental(win.h, _lib.ptr(win.hit), 9, None, b"12", _lib.ptr(win.hit), None, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_window_step_incremental(win.h, None, 3, None, b"12", _lib.ptr(win.hit), None, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_window_step_incremental(win.h, None, 0, None, b"12", None, None, None) == _lib.KWS_ERR_INVALID_ARGUMENT
+    assert lib.kws_window_step_incremental(None, None, 0, None, b"12", _lib.ptr(win.hit), None, None) == _lib.KWS_ERR_INVALID_ARGUMENT
     win.close()
     empty = DeviceWindow(2, 3, 4, True)
     assert empty.step(sm[:2], np.zeros(2, np.uint8), "").tolist() == [1, 1]     # '' occurs in anything (utils/prediction.py:118)
