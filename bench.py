@@ -616,21 +616,27 @@ def main(argv=None, model_factory=None):
     def step():
         model.forward(mel, state, prev_word=prev_word, state_out=state, out=out)
 
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         step()
     device_sync()
+    # shader clock while the timed steps run: sampled once by a helper thread half-way through (estimated from the warm-up),
+    # its sysfs path resolved here -- nothing of it executes inside the timed interval on this thread
+    est_run = (time.perf_counter() - t_w) / max(args.warmup, 1) * args.steps
+    clock = sharding.ClockSampler(device, est_run * 0.5)
     model.set_profiling(True)
     model.kernel_times(reset=True)
     sharding.barrier(dist, sync_device)
     device_sync()
+    clock.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    clock_mhz = sharding.read_sclk_mhz(device)      # sampled while the last steps are still running (sysfs read; None if unreadable)
     device_sync()
     elapsed_own = time.perf_counter() - t0          # this rank alone (per_rank); `value` uses the barrier-to-barrier time
     sharding.barrier(dist, sync_device)
     elapsed = time.perf_counter() - t0
+    clock_mhz = clock.result()                      # None if unreadable as this user
     ktimes = model.kernel_times(reset=True)
     model.set_profiling(False)
     frames, seconds = sharding.reduce_throughput(dist, B * T * args.steps, elapsed, sync_device)

@@ -22,10 +22,10 @@
  *   - plain C types only; every tensor pointer is CALLER-OWNED DEVICE memory (hipMalloc / a PyTorch
  *     tensor's data_ptr) unless the parameter is documented as host memory.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All work is
- *     enqueued asynchronously on it; no entry point synchronises the device except kws_create /
- *     kws_destroy / kws_kernel_times / kws_reserve -- and kws_step only when the call needs more scratch
- *     than kws_reserve or any earlier call provided (it then grows the handle's scratch block, which
- *     waits for the device once; kws_scratch_stats counts those events).
+ *     enqueued asynchronously on it; no entry point synchronises the device except the create / destroy calls,
+ *     kws_kernel_times, kws_reserve, the first kws_window_step of a window (allocates its frame ring) -- and kws_step only
+ *     when the call needs more scratch than kws_reserve or any earlier call provided (it then grows the handle's scratch
+ *     block, which waits for the device once; kws_scratch_stats counts those events).
  *   - return value: KWS_OK or a negative kws_status.  No exceptions, no abort.  The message for the
  *     last failure on the calling thread is kws_last_error().
  *   - a handle is immutable after kws_create except for its scratch buffer and profiling slots: ONE host thread at a
@@ -35,7 +35,11 @@
  *     fully independent (tests/test_gpu_soak.py drives two threads on two handles).  Sharing one handle is detected, not
  *     undefined: a thread that enters kws_step / kws_reserve / kws_kernel_times while another is inside gets KWS_ERR_BUSY
  *     and nothing is launched; calls that are serialised by the caller but arrive on a different stream than the call before
- *     first wait for the device (the previous call's kernels still own the seams), so they are correct, only slower.
+ *     are ordered behind it ON THE DEVICE (every call records an event at its end, the next call's stream waits for it when it
+ *     is another stream): no host wait, nothing that touches other handles' work, legal under stream capture.  (Streams are
+ *     told apart by their handle value: do not destroy a stream with this handle's work still queued and expect a new stream
+ *     that reuses the address to be ordered behind it.)  kws_stream_feed holds its MODEL handle for the whole iteration: stream
+ *     managers that are fed concurrently need a model handle each; any number of them may share one handle when fed in turn.
  */
 #ifndef KWS_AMD_H_
 #define KWS_AMD_H_
@@ -54,7 +58,7 @@ typedef enum kws_status {
     KWS_ERR_HIP = -3,              /* a HIP runtime call failed (message has hipGetErrorString)       */
     KWS_ERR_NO_DEVICE = -4,        /* no gfx950 device visible                                        */
     KWS_ERR_OUT_OF_MEMORY = -5,
-    KWS_ERR_BUSY = -6              /* another host thread is inside kws_step / kws_reserve / kws_kernel_times on this handle */
+    KWS_ERR_BUSY = -6              /* another host thread is inside kws_step / kws_reserve / kws_kernel_times / kws_stream_feed on this handle */
 } kws_status;
 
 /* Model shape: config/rnn_config.py:57-99 (n_mel :63, hidden_size :84, num_layers :76,
@@ -210,7 +214,8 @@ int kws_frontend_mel_basis(kws_frontend_handle h, float* basis_host);
 
 /* Device-side decode window of the streaming loop (detector.py:122,168-209; utils/queue.py): per stream a
  * bounded FIFO of up to `max_chunks` (1..64) softmax chunks (each <= max_frames frames; 2 * max_chunks *
- * round_up(max_frames, 16) bytes must fit 48 KiB, else KWS_ERR_UNSUPPORTED).  ctc_decode2's per-frame rule
+ * round_up(max_frames, 16) bytes must fit 48 KiB, else KWS_ERR_UNSUPPORTED).  The frame ring behind kws_window_step is
+ * allocated by its first call (a window that is only driven incrementally never holds one).  ctc_decode2's per-frame rule
  * (argmax over classes 1..C-2, strictly above `thres`) is a function of the frame alone, so the window stores each
  * frame's word rather than its softmax row; `thres` is therefore fixed per handle.  kws_window_step, per stream:
  *   clear_before[b] != 0 -> empty the window first (silence: detector.py:171-177);
@@ -233,7 +238,9 @@ int kws_window_step(kws_window_handle h, const float* softmax /*[B,T,C]*/, int T
  * pass the same one (KWS_ERR_INVALID_ARGUMENT otherwise).  The incremental state is separate from kws_window_step's frame
  * ring: drive a window through ONE of the two entry points.  kws_stream_feed uses this form -- inside the last GRU layer's
  * launch where that kernel has the tail (fp32 / f16x3 / bf16 stacks at hidden = 128, chunks of <= 64 frames, windows of
- * <= 32 chunks), as a launch of its own otherwise. */
+ * <= 24 chunks) AND every workgroup takes one group of 16 streams (B <= 16 x the device's CUs: 4096 on 256 CUs); as a launch
+ * of its own otherwise.  That launch stages 16 streams' frame words and rings in LDS: 16 * round_up(T, 16) + 256 +
+ * 16 * (32 * max_chunks + 32) bytes must fit 160 KiB, else KWS_ERR_UNSUPPORTED (kws_window_create only sizes the re-scan). */
 int kws_window_step_incremental(kws_window_handle h, const float* softmax /*[B,T,C]*/, int T, const uint8_t* clear_before,
                                 const char* label, int32_t* hit /*[B]*/, uint8_t* restart /*[B] or NULL*/, void* stream);
 
@@ -246,10 +253,14 @@ int kws_window_step_incremental(kws_window_handle h, const float* softmax /*[B,T
  *   on a hit: window cleared, state reset requested for the next chunk                                  (:202-208)
  * i.e. kws_vad -> kws_frontend_run_carry -> kws_step -> kws_window_step_incremental with the mask logic fused into the first
  * kernel, the window step into the last, and no host work per stream: three launches per chunk (gate + front-end, two GRU
- * layers), two for the bf16 stack.  `label` is bound to `window` at kws_stream_create.  The handle BORROWS the model, front-end and window handles (they
- * should outlive it; a feed after one of them was destroyed fails with KWS_ERR_INVALID_ARGUMENT) and the caller-owned
- * device buffers `state` [L,B,H] (zero it to start) and `restart` [B] u8 (zero it); it owns the sample carry, the
- * mel / softmax staging and the masks.  An empty chunk (n == 0) is skipped as detector.py:164-166 does.  Fewer than
+ * layers; two for the bf16 stack) when the window step rides in the last layer's launch (conditions above), one more
+ * (window_inc_kernel) otherwise -- e.g. at B > 16 x CUs.  `label` is bound to `window` at kws_stream_create.  The handle
+ * BORROWS the model, front-end and window handles (they should outlive it; a feed after one of them was destroyed fails with
+ * KWS_ERR_INVALID_ARGUMENT) and the caller-owned device buffers `state` [L,B,H] (zero it to start) and `restart` [B] u8
+ * (zero it).  It OWNS only the sample carry (2 x (fft_size - 1) floats per stream); one chunk's intermediates (mel, softmax,
+ * masks) are carved out of a staging block of the MODEL handle that all its stream handles share, so M managers on one model
+ * cost M x (state + carry + window summaries) -- about 4.8 KB per stream at the reference's shape -- not M x a chunk's
+ * buffers.  An empty chunk (n == 0) is skipped as detector.py:164-166 does.  Fewer than
  * fft_size samples in total so far: the reference still runs its whole iteration on such a chunk, and so does this --
  * the VAD decision clears state and window, every sample is carried, the model runs over zero frames (state handed
  * back, or zeroed where the VAD said silence) and the empty softmax takes a slot of the window before the windowed

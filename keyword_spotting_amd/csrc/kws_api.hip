@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -39,6 +40,12 @@ unsigned long long live_serial(const void* h) {      // 0: not a live handle
     const auto it = g_live.find(h);
     return it == g_live.end() ? 0ull : it->second;
 }
+
+// kws_octbit_matmul's activation-range workspace, one per (device, stream) that has called it (never freed: a few KB each)
+struct OctbitWorkspace { std::mutex mutex; float* p = nullptr; size_t floats = 0; };
+struct PairHash { size_t operator()(const std::pair<int, const void*>& k) const { return std::hash<const void*>()(k.second) * 31u + (size_t)k.first; } };
+std::mutex g_octbit_ws_mutex;
+std::unordered_map<std::pair<int, const void*>, std::unique_ptr<OctbitWorkspace>, PairHash> g_octbit_ws;
 
 int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -125,10 +132,18 @@ struct kws_model {
     // One host thread at a time per handle (kws_amd.h): a second thread that enters kws_step / kws_reserve / kws_kernel_times
     // while another is inside gets KWS_ERR_BUSY instead of racing on the scratch arena and the profiling slots.
     std::atomic<int> in_call{0};
-    // The seams are shared by all calls of the handle: a call that arrives on another HIP stream than the one before waits
-    // for the device first (stream switches are rare; the common path pays nothing).
+    // The seams (and the stream managers' staging below) are shared by all calls of the handle.  Every call records
+    // `last_done` on its stream when its last launch is queued; a call that arrives on ANOTHER HIP stream than the one before
+    // makes its stream wait for that event (device-side ordering: no host stall, nothing that touches other handles' work,
+    // legal under stream capture).  The common path -- same stream as before -- pays one hipEventRecord.
     hipStream_t last_stream = nullptr;
     bool last_stream_valid = false;
+    hipEvent_t last_done = nullptr;
+    // Staging of the stream managers that borrow this handle (kws_stream_feed): widened PCM, mel, softmax and the two masks
+    // of ONE chunk.  They live only inside a feed, feeds of one handle are ordered (one host thread at a time, stream
+    // switches ordered by last_done), so every manager on the handle carves the same block: M managers cost M x their
+    // per-stream state, not M x a chunk's intermediates.  Grows at kws_stream_create only.
+    Arena stage;
     // profiling
     bool profiling = false;
     struct Pending { int slot; hipEvent_t a, b; };
@@ -187,12 +202,20 @@ struct kws_stream {
     char label[17] = {0};
     float* state = nullptr;          // caller-owned [L,B,H]
     uint8_t* restart = nullptr;      // caller-owned [B]
-    float* carry[2] = {nullptr, nullptr};   // [B, fft - 1] each: the carried samples ping-pong
-    float* pcm_f32 = nullptr;        // [B, max_chunk]  int16 input widened here
-    float* mel = nullptr;            // [B, tmax, n_mel]
-    float* softmax = nullptr;        // [B, tmax, C]
-    uint8_t* silent = nullptr;       // [B]
-    uint8_t* reset = nullptr;        // [B]
+    float* carry[2] = {nullptr, nullptr};   // [B, fft - 1] each: the carried samples ping-pong (the only device memory a manager owns)
+    // one chunk's intermediates, carved out of the MODEL handle's staging block (kws_model::stage) at every feed:
+    size_t off_pcm_f32 = 0;          // [B, max_chunk]  int16 input widened here (front-ends other than the 400-point FFT, sub-frame chunks)
+    size_t off_mel = 0;              // [B, tmax, n_mel]
+    size_t off_softmax = 0;          // [B, tmax, C]
+    size_t off_silent = 0;           // [B]
+    size_t off_reset = 0;            // [B]
+    size_t stage_bytes = 0;
+    // the pointers of the current feed
+    float* pcm_f32 = nullptr;
+    float* mel = nullptr;
+    float* softmax = nullptr;
+    uint8_t* silent = nullptr;
+    uint8_t* reset = nullptr;
 };
 
 struct kws_frontend {
@@ -319,7 +342,7 @@ extern "C" {
 const char* kws_version(void) {
     static const std::string v = [] {
         char buf[384];
-        snprintf(buf, sizeof(buf), "kws_amd 0.5 (gfx950; HIP %d.%d.%d; %s; bf16 mfma-vgpr-form=%d; f16x3 mfma-vgpr-form=%d)", HIP_VERSION_MAJOR,
+        snprintf(buf, sizeof(buf), "kws_amd 0.6 (gfx950; HIP %d.%d.%d; %s; bf16 mfma-vgpr-form=%d; f16x3 mfma-vgpr-form=%d" KWS_VARIANT_TAG ")", HIP_VERSION_MAJOR,
                  HIP_VERSION_MINOR, HIP_VERSION_PATCH, __VERSION__, kws::gru_bf16_vgpr_form() ? 1 : 0, kws::gru_f16x3_vgpr_form() ? 1 : 0);
         return std::string(buf);
     }();
@@ -622,6 +645,8 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
     // in the first launch after create).
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { hipFree(m->d_weights); delete m; return hip_fail(e, "hipDeviceSynchronize(weights)"); }
+    e = hipEventCreateWithFlags(&m->last_done, hipEventDisableTiming);
+    if (e != hipSuccess) { hipFree(m->d_weights); delete m; return hip_fail(e, "hipEventCreate"); }
     m->ms_sum.assign(cfg->num_layers, 0.f);
     m->launches.assign(cfg->num_layers, 0);
     live_register(m);
@@ -650,6 +675,8 @@ int kws_destroy(kws_handle h) {
     if (h->d_weights) hipFree(h->d_weights);
     if (h->arena.base) hipFree(h->arena.base);
     if (h->arena_fine.base) hipFree(h->arena_fine.base);
+    if (h->stage.base) hipFree(h->stage.base);
+    if (h->last_done) hipEventDestroy(h->last_done);
     if (h->pipe_ready) hipFree(h->pipe_ready);
     // a layer-pipelined step that timed out and was never followed by another call is still reported, once
     const bool pipe_failed = h->pipe_error_host && *reinterpret_cast<volatile int*>(h->pipe_error_host) != 0;
@@ -984,7 +1011,19 @@ static bool step_takes_window(kws_handle h, int B, int T, int window_chunks) {
 
 static int step_impl(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
                      float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
-                     int32_t* prev_word, float decode2_thres, int B, int T, void* stream, const kws::WindowTail* wt);
+                     int32_t* prev_word, float decode2_thres, int B, int T, void* stream, const kws::WindowTail* wt, bool locked = false);
+
+// Ordering of a call against the handle's previous one (kws_model::last_done): device-side, never a host wait.
+static int call_enter(kws_handle h, hipStream_t st) {
+    if (h->last_stream_valid && st != h->last_stream) KWS_HIP(hipStreamWaitEvent(st, h->last_done, 0));
+    h->last_stream = st;
+    h->last_stream_valid = true;
+    return KWS_OK;
+}
+static int call_leave(kws_handle h, hipStream_t st) {
+    KWS_HIP(hipEventRecord(h->last_done, st));
+    return KWS_OK;
+}
 
 int kws_step(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
              float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
@@ -993,9 +1032,14 @@ int kws_step(kws_handle h, const float* mel, const float* state_in, float* logit
 }
 
 // wt: the stream manager's decode window, to ride at the end of the last layer's launch (step_takes_window said yes)
+static int step_body(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
+                     float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
+                     int32_t* prev_word, float decode2_thres, int B, int T, hipStream_t st, const kws::WindowTail* wt);
+
+// locked: the caller (kws_stream_feed) already holds the handle and has ordered `stream` behind its previous call
 static int step_impl(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
                      float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
-                     int32_t* prev_word, float decode2_thres, int B, int T, void* stream, const kws::WindowTail* wt) {
+                     int32_t* prev_word, float decode2_thres, int B, int T, void* stream, const kws::WindowTail* wt, bool locked) {
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
     if (wt && (seq_len || !step_takes_window(h, B, T, wt->nq))) return fail(KWS_ERR_UNSUPPORTED, "internal: this step cannot take a window tail");
     if (B < 0 || T < 0) return fail(KWS_ERR_INVALID_ARGUMENT, "negative B=%d or T=%d", B, T);
@@ -1003,15 +1047,23 @@ static int step_impl(kws_handle h, const float* mel, const float* state_in, floa
     if (!state_in || !state_out) return fail(KWS_ERR_INVALID_ARGUMENT, "state_in/state_out must not be null");
     if (tokens && !prev_word) return fail(KWS_ERR_INVALID_ARGUMENT, "tokens requires prev_word");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const kws_config& c = h->cfg;
-    const int H = c.hidden, L = c.num_layers;
+    if (locked) return step_body(h, mel, state_in, logits, softmax, state_out, seq_len, reset_mask, tokens, prev_word, decode2_thres, B, T, st, wt);
     BusyGuard busy(h->in_call);
     if (!busy.owned)
         return fail(KWS_ERR_BUSY, "kws_step: another host thread is inside a call on this handle (one thread at a time per handle; "
                     "use one handle per thread)");
-    if (h->last_stream_valid && st != h->last_stream) KWS_HIP(hipDeviceSynchronize());     // the previous call's kernels still own the seams
-    h->last_stream = st;
-    h->last_stream_valid = true;
+    int rc = call_enter(h, st);       // the previous call's kernels may still own the seams: this stream waits for them on the device
+    if (rc != KWS_OK) return rc;
+    rc = step_body(h, mel, state_in, logits, softmax, state_out, seq_len, reset_mask, tokens, prev_word, decode2_thres, B, T, st, wt);
+    const int rl = call_leave(h, st);     // also after a failure: whatever was queued before it is what the next call must wait for
+    return rc != KWS_OK ? rc : rl;
+}
+
+static int step_body(kws_handle h, const float* mel, const float* state_in, float* logits, float* softmax,
+                     float* state_out, const int32_t* seq_len, const uint8_t* reset_mask, int8_t* tokens,
+                     int32_t* prev_word, float decode2_thres, int B, int T, hipStream_t st, const kws::WindowTail* wt) {
+    const kws_config& c = h->cfg;
+    const int H = c.hidden, L = c.num_layers;
     {
         const int rc = check_pipe_error(h);      // raised by an earlier layer-pipelined step of this handle
         if (rc != KWS_OK) return rc;
@@ -1263,11 +1315,9 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres,
     if (!wnd) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
     wnd->B = B; wnd->nq = max_chunks; wnd->tmax = max_frames; wnd->tmax_pad = (max_frames + 15) & ~15; wnd->C = C;
     wnd->thres = thres;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&wnd->words), (size_t)B * max_chunks * wnd->tmax_pad);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->lens), (size_t)B * max_chunks * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->head), (size_t)B * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->count), (size_t)B * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_tab), (size_t)B * max_chunks * 32);
+    // the summaries of the incremental form (what kws_stream_feed drives: 32 + 4 bytes per queued chunk and stream); the frame
+    // ring of the re-scanning kws_window_step (tmax_pad + 4 bytes per queued chunk) is allocated by its first call
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_tab), (size_t)B * max_chunks * 32);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_meta), (size_t)B * max_chunks * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_head), (size_t)B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&wnd->inc_count), (size_t)B * sizeof(int));
@@ -1275,7 +1325,6 @@ int kws_window_create(int B, int max_chunks, int max_frames, int C, float thres,
     if (e == hipSuccess) e = hipMemset(wnd->inc_tab, 0, (size_t)B * max_chunks * 32);
     if (e == hipSuccess) e = hipMemset(wnd->inc_meta, 0, (size_t)B * max_chunks * sizeof(uint32_t));
     if (e == hipSuccess) e = kws::launch_window_reset(B, wnd->inc_head, wnd->inc_count, nullptr);
-    if (e == hipSuccess) e = kws::launch_window_reset(B, wnd->head, wnd->count, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { kws_window_destroy(wnd); return hip_fail(e, "kws_window_create"); }
     live_register(wnd);
@@ -1314,6 +1363,19 @@ int kws_window_step(kws_window_handle h, const float* softmax, int T, const uint
         p.label[i] = label[i] - '0';
     }
     p.label_len = n;
+    if (!h->words) {          // first re-scanning step of this window: its frame ring (synchronises once)
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->words), (size_t)h->B * h->nq * h->tmax_pad);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->lens), (size_t)h->B * h->nq * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->head), (size_t)h->B * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->count), (size_t)h->B * sizeof(int));
+        if (e == hipSuccess) e = kws::launch_window_reset(h->B, h->head, h->count, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            for (void* q : {(void*)h->words, (void*)h->lens, (void*)h->head, (void*)h->count}) if (q) hipFree(q);
+            h->words = nullptr; h->lens = nullptr; h->head = nullptr; h->count = nullptr;
+            return hip_fail(e, "hipMalloc(window frame ring)");
+        }
+    }
     p.words = h->words; p.lens = h->lens; p.head = h->head; p.count = h->count;
     p.softmax = softmax; p.clear_before = clear_before; p.hit = hit; p.restart = restart;
     p.thres = h->thres; p.B = h->B; p.T = T; p.C = h->C; p.nq = h->nq; p.tmax = h->tmax_pad;
@@ -1338,6 +1400,14 @@ static void window_label_delta(const char* label, int n, uint8_t* delta) {
             delta[q * 16 + w] = (uint8_t)k;
         }
 }
+
+// LDS of window_inc_kernel for chunks of T frames (launch_window_inc, stream_kernels.hip): the 16 streams' frame words, the label
+// matcher, the rings.  kws_window_create only sizes the re-scanning kernel; the incremental entry points check this one.
+static size_t window_inc_lds_bytes(int T, int nq) {
+    const int stride = (T + 15) & ~15;
+    return (size_t)16 * (stride > 0 ? stride : 16) + 256 + kws::window_tail_scratch_bytes(nq);
+}
+constexpr size_t kWindowIncLdsMax = 160 * 1024;
 
 // Binds `label` to the window's incremental state (the queued summaries are label-specific).  The first binding uploads the
 // matcher (synchronises); the same label again is free; another label while chunks may be queued is refused.
@@ -1372,6 +1442,10 @@ int kws_window_step_incremental(kws_window_handle h, const float* softmax, int T
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
     if (T < 0 || T > h->tmax) return fail(KWS_ERR_INVALID_ARGUMENT, "T=%d outside [0,%d]", T, h->tmax);
     if (!hit || (!softmax && T > 0) || !label) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
+    if (window_inc_lds_bytes(T, h->nq) > kWindowIncLdsMax)
+        return fail(KWS_ERR_UNSUPPORTED, "the incremental window step stages 16 streams x %d frame words and their %d-chunk rings in LDS: %zu bytes "
+                    "exceed the %zu a workgroup may hold (shorter chunks, or kws_window_step, which re-scans the frames)", T, h->nq,
+                    window_inc_lds_bytes(T, h->nq), kWindowIncLdsMax);
     const int rc = window_bind_label(h, label);
     if (rc != KWS_OK) return rc;
     kws::WindowIncParams p;
@@ -1588,7 +1662,7 @@ int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window
     if (!ms || !fs || !ws) return fail(KWS_ERR_INVALID_ARGUMENT, "model, front-end or window handle is not alive (destroyed, or not a handle)");
     if (B < 1 || max_chunk_samples < 1) return fail(KWS_ERR_INVALID_ARGUMENT, "bad stream shape B=%d max_chunk_samples=%d", B, max_chunk_samples);
     const int n = (int)strlen(label);
-    if (n > 16) return fail(KWS_ERR_INVALID_ARGUMENT, "label longer than 16 digits");
+    if (n > 15) return fail(KWS_ERR_INVALID_ARGUMENT, "label longer than 15 digits (the incremental window's matcher has 16 states)");
     for (int i = 0; i < n; ++i)
         if (label[i] < '1' || label[i] > '9') return fail(KWS_ERR_INVALID_ARGUMENT, "label must be digits 1..9, got '%s'", label);
     if (frontend->cfg.n_mel != model->cfg.n_mel)
@@ -1601,6 +1675,9 @@ int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window
     if (tmax > window->tmax)
         return fail(KWS_ERR_INVALID_ARGUMENT, "chunks of %d samples give up to %d frames, the window holds %d per chunk", max_chunk_samples,
                     tmax, window->tmax);
+    if (window_inc_lds_bytes(tmax, window->nq) > kWindowIncLdsMax)
+        return fail(KWS_ERR_UNSUPPORTED, "chunks of up to %d frames with a %d-chunk window need %zu bytes of LDS in the incremental window step "
+                    "(limit %zu): use shorter chunks", tmax, window->nq, window_inc_lds_bytes(tmax, window->nq), kWindowIncLdsMax);
     kws_stream* s = new (std::nothrow) kws_stream();
     if (!s) return fail(KWS_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->model_serial = ms; s->fe_serial = fs; s->win_serial = ws;
@@ -1610,13 +1687,34 @@ int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window
     const size_t carry_bytes = (size_t)B * (fft - 1) * sizeof(float);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->carry[0]), carry_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->carry[1]), carry_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->pcm_f32), (size_t)B * max_chunk_samples * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->mel), (size_t)B * (tmax > 0 ? tmax : 1) * model->cfg.n_mel * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->softmax), (size_t)B * (tmax > 0 ? tmax : 1) * model->cfg.num_classes * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->silent), (size_t)B);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->reset), (size_t)B);
     if (e != hipSuccess) { kws_stream_destroy(s); return hip_fail(e, "hipMalloc(stream buffers)"); }
-    int rc = kws_reserve(model, B, tmax);            // the GRU step of a chunk never allocates afterwards
+    // One chunk's intermediates come out of the model handle's staging block: sized here, so a feed never allocates.  The
+    // widened copy of int16 PCM is read by the dense-DFT front-end only (the 400-point FFT reads int16 in place); with the
+    // FFT front-end it is written just by the gate of a chunk that completes no frame (< fft samples in total).
+    {
+        auto take = [&](size_t bytes) { const size_t at = s->stage_bytes; s->stage_bytes += (bytes + 255) & ~size_t(255); return at; };
+        const size_t tm = (size_t)(tmax > 0 ? tmax : 1);
+        const bool fused_gate = frontend->use_fft && (long long)B * tm < (1LL << 31);        // frontend_fuses_gate for every chunk with a frame
+        s->off_pcm_f32 = take((size_t)B * (fused_gate ? std::min(max_chunk_samples, fft - 1) : max_chunk_samples) * sizeof(float));
+        s->off_mel = take((size_t)B * tm * model->cfg.n_mel * sizeof(float));
+        s->off_softmax = take((size_t)B * tm * model->cfg.num_classes * sizeof(float));
+        s->off_silent = take((size_t)B);
+        s->off_reset = take((size_t)B);
+    }
+    int rc = KWS_OK;
+    {
+        BusyGuard busy(model->in_call);
+        if (!busy.owned) rc = fail(KWS_ERR_BUSY, "kws_stream_create: another host thread is inside a call on the model handle");
+        else if (s->stage_bytes > model->stage.bytes) {
+            // grows only here; the old block may still be read by a feed in flight
+            hipError_t es = hipDeviceSynchronize();
+            if (es == hipSuccess && model->stage.base) { hipFree(model->stage.base); model->stage.base = nullptr; model->stage.bytes = 0; }
+            if (es == hipSuccess) es = hipMalloc(reinterpret_cast<void**>(&model->stage.base), s->stage_bytes);
+            if (es != hipSuccess) { model->stage.base = nullptr; rc = hip_fail(es, "hipMalloc(stream staging)"); }
+            else { model->stage.bytes = s->stage_bytes; ++model->scratch_allocs; }
+        }
+    }
+    if (rc == KWS_OK) rc = kws_reserve(model, B, tmax);            // the GRU step of a chunk never allocates afterwards
     if (rc == KWS_OK) rc = window_bind_label(window, s->label);      // the window's summaries are built for this label
     if (rc != KWS_OK) { kws_stream_destroy(s); return rc; }
     *out = s;
@@ -1626,9 +1724,7 @@ int kws_stream_create(kws_handle model, kws_frontend_handle frontend, kws_window
 int kws_stream_destroy(kws_stream_handle h) {
     if (!h) return KWS_OK;
     hipDeviceSynchronize();
-    for (float* p : {h->carry[0], h->carry[1], h->pcm_f32, h->mel, h->softmax}) if (p) hipFree(p);
-    if (h->silent) hipFree(h->silent);
-    if (h->reset) hipFree(h->reset);
+    for (float* p : {h->carry[0], h->carry[1]}) if (p) hipFree(p);
     delete h;
     return KWS_OK;
 }
@@ -1639,6 +1735,8 @@ int kws_stream_reset(kws_stream_handle h) {
     return KWS_OK;
 }
 
+static int stream_feed_locked(kws_stream_handle h, const void* pcm, int n, int pcm_int16, int32_t* hit, hipStream_t st);
+
 int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, int32_t* hit, void* stream) {
     if (!h) return fail(KWS_ERR_INVALID_ARGUMENT, "handle is null");
     if (n < 0 || n > h->max_chunk) return fail(KWS_ERR_INVALID_ARGUMENT, "chunk of %d samples outside [0,%d]", n, h->max_chunk);
@@ -1646,16 +1744,38 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
     if (live_serial(h->model) != h->model_serial || live_serial(h->fe) != h->fe_serial || live_serial(h->win) != h->win_serial)
         return fail(KWS_ERR_INVALID_ARGUMENT, "the model, front-end or window this stream was created on has been destroyed");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == 0) {            // detector.py:164-166: an empty read is skipped before anything else happens
+        KWS_HIP(hipMemsetAsync(hit, 0, (size_t)h->B * sizeof(int32_t), st));
+        return KWS_OK;
+    }
+    // The feed holds the model handle from its first launch to its last (the staging and the seams are the handle's), and
+    // orders `stream` behind the handle's previous call when that ran on another stream.
+    kws_model* model = h->model;
+    BusyGuard busy(model->in_call);
+    if (!busy.owned)
+        return fail(KWS_ERR_BUSY, "kws_stream_feed: another host thread is inside a call on the model handle (one thread at a time per "
+                    "handle; stream managers that run concurrently need a model handle each)");
+    if (h->stage_bytes > model->stage.bytes) return fail(KWS_ERR_INVALID_ARGUMENT, "internal: the model handle's staging block is smaller than this stream's");
+    int rc = call_enter(model, st);
+    if (rc != KWS_OK) return rc;
+    h->pcm_f32 = reinterpret_cast<float*>(model->stage.base + h->off_pcm_f32);
+    h->mel = reinterpret_cast<float*>(model->stage.base + h->off_mel);
+    h->softmax = reinterpret_cast<float*>(model->stage.base + h->off_softmax);
+    h->silent = reinterpret_cast<uint8_t*>(model->stage.base + h->off_silent);
+    h->reset = reinterpret_cast<uint8_t*>(model->stage.base + h->off_reset);
+    rc = stream_feed_locked(h, pcm, n, pcm_int16, hit, st);
+    const int rl = call_leave(model, st);
+    return rc != KWS_OK ? rc : rl;
+}
+
+// one iteration with the model handle held and `st` ordered (kws_stream_feed above)
+static int stream_feed_locked(kws_stream_handle h, const void* pcm, int n, int pcm_int16, int32_t* hit, hipStream_t st) {
     const kws_frontend_config& fc = h->fe->cfg;
     const int fft = fc.fft_size, hop = fc.hop_size, B = h->B;
     const int total = h->n_carry + n;
     const float* chunk = pcm_int16 ? h->pcm_f32 : static_cast<const float*>(pcm);
     const float* carry = h->carry[h->cur];
     float* next = h->carry[h->cur ^ 1];
-    if (n == 0) {            // detector.py:164-166: an empty read is skipped before anything else happens
-        KWS_HIP(hipMemsetAsync(hit, 0, (size_t)B * sizeof(int32_t), st));
-        return KWS_OK;
-    }
     if (total < fft) {
         // Not a full frame yet.  The reference still runs the whole iteration on such a chunk (detector.py:168-209): vad ->
         // clean_state() + prob_queue.clear() when silent, the samples are carried (:179-183 keeps all of them), sess.run over
@@ -1664,7 +1784,7 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
         hipError_t e = kws::launch_vad_gate(pcm, pcm_int16, B, n, h->vad_thres, h->pcm_f32, h->restart, h->silent, h->reset,
                                             h->n_carry ? carry : nullptr, h->n_carry, next, total, st);
         if (e != hipSuccess) return hip_fail(e, "launch vad_gate");
-        int rc = kws_step(h->model, nullptr, h->state, nullptr, nullptr, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, 0, st);
+        int rc = step_impl(h->model, nullptr, h->state, nullptr, nullptr, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, 0, st, nullptr, true);
         if (rc != KWS_OK) return rc;
         rc = kws_window_step_incremental(h->win, nullptr, 0, h->silent, h->label, hit, h->restart, st);
         if (rc != KWS_OK) return rc;
@@ -1695,10 +1815,10 @@ int kws_stream_feed(kws_stream_handle h, const void* pcm, int n, int pcm_int16, 
         // the frame words its flush has just produced -- no softmax round trip, no fourth launch.  The window's threshold
         // is the fused decoder's (ctc_decode2's frame rule, utils/prediction.py:74)
         const kws::WindowTail wt = window_tail_params(h->win, h->silent, hit, h->restart);
-        rc = step_impl(h->model, h->mel, h->state, nullptr, nullptr, h->state, nullptr, h->reset, nullptr, nullptr, h->win->thres, B, T, st, &wt);
+        rc = step_impl(h->model, h->mel, h->state, nullptr, nullptr, h->state, nullptr, h->reset, nullptr, nullptr, h->win->thres, B, T, st, &wt, true);
         if (rc != KWS_OK) return rc;
     } else {
-        rc = kws_step(h->model, h->mel, h->state, nullptr, h->softmax, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, T, st);
+        rc = step_impl(h->model, h->mel, h->state, nullptr, h->softmax, h->state, nullptr, h->reset, nullptr, nullptr, 0.f, B, T, st, nullptr, true);
         if (rc != KWS_OK) return rc;
         rc = kws_window_step_incremental(h->win, h->softmax, T, h->silent, h->label, hit, h->restart, st);
         if (rc != KWS_OK) return rc;
@@ -1763,12 +1883,31 @@ int kws_octbit_matmul(const float* x, const int8_t* Wq, float scale_w, const flo
     if (K == 0) return fail(KWS_ERR_INVALID_ARGUMENT, "K must be positive");
     if (!x || !Wq || !bias || !out) return fail(KWS_ERR_INVALID_ARGUMENT, "null pointer argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float* ws = nullptr;
-    KWS_HIP(hipMallocAsync(reinterpret_cast<void**>(&ws), (size_t)(2 * A + 2) * sizeof(float), st));
-    hipError_t e = kws::launch_octbit_matmul(x, Wq, scale_w, bias, out, A, K, N, per_row_scale, ws, st);
-    hipError_t e2 = hipFreeAsync(ws, st);
+    // The 2A+2 floats of activation ranges come from a block cached per (device, stream): the reference's Compute allocates its
+    // temporaries per call (octbit_mat_mul_op.cc:49, re-entrant); here a call neither allocates nor frees once its stream has
+    // seen a call of this size.  Calls on one stream are ordered by the stream; two host threads that share a stream are
+    // serialised on the block's own mutex for the duration of the two launches.
+    int dev = 0;
+    KWS_HIP(hipGetDevice(&dev));
+    OctbitWorkspace* w = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_octbit_ws_mutex);
+        std::unique_ptr<OctbitWorkspace>& slot = g_octbit_ws[std::make_pair(dev, (const void*)st)];
+        if (!slot) slot.reset(new OctbitWorkspace());
+        w = slot.get();
+    }
+    std::lock_guard<std::mutex> use(w->mutex);
+    const size_t need = (size_t)(2 * A + 2);
+    if (need > w->floats) {
+        // stream-ordered: the old block is released behind the launches that still read it
+        float* grown = nullptr;
+        KWS_HIP(hipMallocAsync(reinterpret_cast<void**>(&grown), need * sizeof(float), st));
+        if (w->p) (void)hipFreeAsync(w->p, st);
+        w->p = grown;
+        w->floats = need;
+    }
+    hipError_t e = kws::launch_octbit_matmul(x, Wq, scale_w, bias, out, A, K, N, per_row_scale, w->p, st);
     if (e != hipSuccess) return hip_fail(e, "launch octbit_matmul");
-    if (e2 != hipSuccess) return hip_fail(e2, "hipFreeAsync");
     return KWS_OK;
 }
 

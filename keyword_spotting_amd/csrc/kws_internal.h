@@ -7,6 +7,44 @@
 
 #include "kws_amd.h"
 
+// Experiment / test switches compiled into the kernel sources (timing counters, ablations, the self-test's negative control).
+// A product build defines none of them; tools/build_variant.sh -- the only place that defines KWS_VARIANT_BUILD -- passes them
+// to every translation unit, so kws_version() of such a library names them (KWS_VARIANT_TAG) and a stray -D in a product
+// build does not compile.
+#if defined(KWS_FAULT_INJECT) || defined(KWS_ABL_NOFLUSH) || defined(KWS_ABL_NOMEL) || defined(KWS_F16_TIMING) || defined(KWS_FE_TIMING) || \
+    defined(KWS_FE_OCC) || defined(KWS_FE_FT) || defined(KWS_FE_SF) || defined(KWS_FE_NOSTAGE) || defined(KWS_FE_NODFT) || defined(KWS_FE_NOMEL) || \
+    defined(KWS_OABL_NODIV) || defined(KWS_OABL_NODOT) || defined(KWS_OVERLAP_MIN_T)
+#ifndef KWS_VARIANT_BUILD
+#error "an experiment switch (KWS_FAULT_INJECT / KWS_ABL_* / KWS_*_TIMING / KWS_FE_* / KWS_OABL_* / KWS_OVERLAP_MIN_T) is defined in a product build: use tools/build_variant.sh"
+#endif
+#endif
+#ifdef KWS_VARIANT_BUILD
+#define KWS_VARIANT_TAG_1(name) "; " #name
+#ifdef KWS_FAULT_INJECT
+#define KWS_TAG_FAULT KWS_VARIANT_TAG_1(FAULT_INJECT)
+#else
+#define KWS_TAG_FAULT ""
+#endif
+#ifdef KWS_ABL_NOFLUSH
+#define KWS_TAG_NOFLUSH KWS_VARIANT_TAG_1(ABL_NOFLUSH)
+#else
+#define KWS_TAG_NOFLUSH ""
+#endif
+#ifdef KWS_ABL_NOMEL
+#define KWS_TAG_NOMEL KWS_VARIANT_TAG_1(ABL_NOMEL)
+#else
+#define KWS_TAG_NOMEL ""
+#endif
+#if defined(KWS_F16_TIMING) || defined(KWS_FE_TIMING)
+#define KWS_TAG_TIMING KWS_VARIANT_TAG_1(TIMING)
+#else
+#define KWS_TAG_TIMING ""
+#endif
+#define KWS_VARIANT_TAG "; VARIANT BUILD" KWS_TAG_FAULT KWS_TAG_NOFLUSH KWS_TAG_NOMEL KWS_TAG_TIMING
+#else
+#define KWS_VARIANT_TAG ""
+#endif
+
 namespace kws {
 
 constexpr int kStreamsPerGroup = 16;  // MFMA N dimension: one workgroup advances 16 streams

@@ -3,6 +3,7 @@ path), so a batch is partitioned across ranks with NO data-path collective.  tor
 (RCCL over xGMI on the GPU box, gloo in CPU tests) is used only for the timing barrier and the
 8-byte throughput reduction."""
 import os
+import time
 
 
 def env_rank_world():
@@ -72,9 +73,9 @@ def rank_identity(rank, local_rank, device, frames_per_s):
     return info
 
 
-def read_sclk_mhz(device):
-    """Current shader clock of `device` in MHz from sysfs (the starred line of pp_dpm_sclk of the DRM card with the device's
-    PCI address), or None: not a GPU, not readable as this user, or no such file.  Informational only (bench.py per_rank)."""
+def find_sclk_path(device):
+    """sysfs file with the shader-clock table of `device` (pp_dpm_sclk of the DRM card with the device's PCI address), or
+    None: not a GPU, or no such file.  Resolved once, OUTSIDE any timed region (imports, a device-property query, a glob)."""
     if getattr(device, "type", "cpu") != "cuda":
         return None
     try:
@@ -86,17 +87,55 @@ def read_sclk_mhz(device):
         for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             try:
                 slot = re.search(r"PCI_SLOT_NAME=(\S+)", open(os.path.join(card, "uevent")).read())
-                if not slot or not slot.group(1).lower().startswith(want):
-                    continue
-                for ln in open(os.path.join(card, "pp_dpm_sclk")):
-                    m = re.match(r"\s*\d+:\s*(\d+)\s*[Mm][Hh]z\s*\*", ln)
-                    if m:
-                        return int(m.group(1))
+                if slot and slot.group(1).lower().startswith(want) and os.path.exists(os.path.join(card, "pp_dpm_sclk")):
+                    return os.path.join(card, "pp_dpm_sclk")
             except Exception:
                 continue
     except Exception:
         pass
     return None
+
+
+def read_sclk_file(path):
+    """The starred line of a pp_dpm_sclk file in MHz, or None (not readable as this user)."""
+    import re
+    try:
+        for ln in open(path):
+            m = re.match(r"\s*\d+:\s*(\d+)\s*[Mm][Hh]z\s*\*", ln)
+            if m:
+                return int(m.group(1))
+    except Exception:
+        pass
+    return None
+
+
+def read_sclk_mhz(device):
+    """Current shader clock of `device` in MHz, or None.  Informational only (bench.py per_rank)."""
+    path = find_sclk_path(device)
+    return read_sclk_file(path) if path else None
+
+
+class ClockSampler(object):
+    """Samples the shader clock ONCE, `delay_s` after start(), from a helper thread: the timed loop of bench.py never
+    executes the sysfs read itself (the read is an SMU query; done inline it sat inside the timed interval)."""
+
+    def __init__(self, device, delay_s):
+        import threading
+        self.path, self.delay_s, self.value = find_sclk_path(device), max(0.0, float(delay_s)), None
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.path else None
+
+    def _run(self):
+        time.sleep(self.delay_s)
+        self.value = read_sclk_file(self.path)
+
+    def start(self):
+        if self._thread is not None:
+            self._thread.start()
+
+    def result(self):
+        if self._thread is not None:
+            self._thread.join(2.0)
+        return self.value
 
 
 def gather_rank_info(dist, info):

@@ -198,3 +198,33 @@ def test_selftest_catches_a_miscompiled_build():
     assert any(ln.startswith("PASS") and "f16x3" in ln for ln in lines), lines       # kernels the fault does not touch (own activation code) still pass
     lines = _run_selftest_process({"KWS_AMD_LIB": so, "KWS_SELFTEST": "1"})             # refused at kws_create
     assert any(ln.startswith("FAIL") and "kws_selftest" in ln for ln in lines), lines
+
+
+def test_register_allocation_guard_fails_the_build_on_a_spill(tmp_path):
+    """tools/check_spills.sh (run by csrc/Makefile after every link) compares the code-object metadata of the hot
+    instantiations with csrc/spill_expectations.txt: the committed build passes; an allocation that differs from the
+    committed one -- simulated here by expecting one spill LESS / one MORE than the build has -- and a listed kernel that no
+    longer exists make it exit non-zero, which the Makefile turns into a failed link."""
+    import subprocess
+    csrc = os.path.join(ROOT, "keyword_spotting_amd", "csrc")
+    script, exp = os.path.join(ROOT, "tools", "check_spills.sh"), os.path.join(csrc, "spill_expectations.txt")
+    if not os.path.isdir(os.path.join(csrc, "_obj")):
+        pytest.skip("no object files (library built elsewhere)")
+    ok = subprocess.run([script, os.path.join(csrc, "_obj"), exp], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stdout + ok.stderr
+    assert "gru_layer_resident<32, false, true, false>" in ok.stdout
+    lines = open(exp).read().splitlines()
+    for mutate in ("vgpr", "scratch", "missing"):
+        out = []
+        for ln in lines:
+            if ln.startswith("kws::gru_layer_resident<32, false, true, false>|"):
+                ln = {"vgpr": "kws::gru_layer_resident<32, false, true, false>|1|0|0",
+                      "scratch": ln, "missing": "kws::gru_layer_resident<33, false, true, false>|0|0|0"}[mutate]
+            if mutate == "scratch" and ln.startswith("kws::gru_layer_resident<32, false, true, true>|"):
+                ln = "kws::gru_layer_resident<32, false, true, true>|0|0|0"        # the build has SGPR spills and 28 B of scratch there
+            out.append(ln)
+        bad = tmp_path / ("exp_%s.txt" % mutate)
+        bad.write_text("\n".join(out) + "\n")
+        r = subprocess.run([script, os.path.join(csrc, "_obj"), str(bad)], capture_output=True, text=True)
+        assert r.returncode != 0, (mutate, r.stdout)
+        assert "check_spills" in r.stdout

@@ -301,3 +301,78 @@ def test_sharing_one_handle_between_threads_is_detected_not_undefined():
             # next call on the other stream -- kws_step waits for the device when the stream changes, so results stay right
             assert not bad, "%d corrupted results out of %d" % (len(bad), stats["ok"])
     m.close()
+
+
+def test_a_stream_switch_is_ordered_on_the_device_and_does_not_drain_other_handles():
+    """A handle whose calls alternate between two HIP streams is ordered by an event on its own last launch (kws_amd.h) -- not by a
+    device-wide wait, which would block the calling thread until every OTHER handle's queue has drained.  Thread B keeps ~100 ms of
+    4096 x 300 steps queued on its handle; meanwhile thread A's 24 alternating small calls must return in a fraction of that
+    time (loose bound), and both get the bits of running alone."""
+    import threading
+    import time
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    cfg = get_config()
+    wa, wb = G.random_weights(40, 128, 2, 6, seed=621), G.random_weights(40, 128, 2, 6, seed=622)
+    ba, ta, bb, tb, nb = 96, 22, 4096, 300, 32
+    mel_a = [torch.from_numpy(G.synthetic_mel(ba, ta, 40, seed=623 + k)).cuda() for k in range(3)]
+    mel_b = (torch.randn(bb, tb, 40, device="cuda").abs() * 2).contiguous()
+
+    def a_calls(m, streams):
+        st, pw = m.zero_state(ba), m.fresh_prev_word(ba)
+        acc = torch.zeros(ba, ta, 6, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(24):
+            with torch.cuda.stream(streams[k % len(streams)]):
+                r = m.forward(mel_a[k % 3], st, prev_word=pw, state_out=st)
+        host_s = time.perf_counter() - t0                   # the calls only: nothing below is timed
+        torch.cuda.synchronize()
+        return host_s, r["logits"].cpu(), st.cpu(), pw.cpu()
+
+    def b_calls(m, stream, started):
+        st = m.zero_state(bb)
+        out = {"logits": torch.empty(bb, tb, 6, device="cuda"), "softmax": torch.empty(bb, tb, 6, device="cuda")}
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for k in range(nb):
+                m.forward(mel_b, st, state_out=st, out=out)
+                if k == 3:
+                    started.set()
+        return st, out
+
+    # alone
+    ma, mb = DeployModel(cfg, wa), DeployModel(cfg, wb)
+    mb.reserve(bb, tb)
+    _, want_l, want_s, want_p = a_calls(ma, [torch.cuda.current_stream()])
+    stb, _ = b_calls(mb, torch.cuda.current_stream(), threading.Event())
+    torch.cuda.synchronize()
+    want_b = stb.cpu()
+    ma.close(); mb.close()
+    # together: B's queue is deep while A alternates streams
+    ma, mb = DeployModel(cfg, wa), DeployModel(cfg, wb)
+    mb.reserve(bb, tb)
+    ma.forward(mel_a[0], ma.zero_state(ba))              # A's scratch is sized before the race
+    torch.cuda.synchronize()
+    started, box = threading.Event(), {}
+    sb = torch.cuda.Stream()
+    th = threading.Thread(target=lambda: box.setdefault("b", b_calls(mb, sb, started)))
+    t0 = time.perf_counter()
+    th.start()
+    assert started.wait(60)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    st, pw = ma.zero_state(ba), ma.fresh_prev_word(ba)        # (allocated on the default stream while B runs: no sync here)
+    ta0 = time.perf_counter()
+    for k in range(24):
+        with torch.cuda.stream((s1, s2)[k % 2]):
+            r = ma.forward(mel_a[k % 3], st, prev_word=pw, state_out=st)
+    host_s = time.perf_counter() - ta0
+    th.join(120)
+    sb.synchronize()
+    drain_s = time.perf_counter() - t0                    # B's 32 steps, about 100 ms of device time
+    torch.cuda.synchronize()
+    assert torch.equal(r["logits"].cpu(), want_l) and torch.equal(st.cpu(), want_s) and torch.equal(pw.cpu(), want_p)
+    assert torch.equal(box["b"][0].cpu(), want_b)
+    assert drain_s > 0.05, drain_s
+    assert host_s < 0.5 * drain_s, "A's calls took %.1f ms of host time while B's queue drained in %.1f ms: a stream switch waited for the device" % (host_s * 1e3, drain_s * 1e3)
+    ma.close(); mb.close()

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""BASELINE.json's metric as worded: "real-time audio streams SUSTAINED (10 ms hop)" on one GPU.
+
+N = M x S DISTINCT streams are resident on the device (state + sample carry + decode window of every one, and -- device-fed
+variant -- one 225 ms int16 PCM chunk per manager of its own); every 225 ms period (detector.py:119: 3600 samples at 16 kHz)
+each of the M StreamManagers is fed its chunk through kws_stream_feed, M native calls issued in turn on `handles` HIP streams
+(one model handle each).  A period is on time when every manager's trigger decisions are on the device before the next
+chunks are due.  Reported: the largest N that ran `periods` periods (>= 9 s) with ZERO deadline misses, the p50 / p99 / max
+period compute time, device bytes per stream, launches per period -- and beside it the HOST-FED variant (chunks start in
+pinned host memory, uploads on a copy stream per handle overlapped with compute; PCIe-bound, never bench.py's `value`).
+
+  python tools/bench_serve.py [--precision fp32|f16x3|bf16|int8] [--streams-per-manager 16384] [--handles 2] [--periods 40]
+                              [--host-fed] [--json]
+bench.py imports sustained_streams() for its `secondary` entries.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PERIOD_S = 0.225          # detector.py:119
+CHUNK = 3600              # samples per period and stream
+
+
+def _pcm(server, n_managers, device, gen):
+    """One int16 chunk per manager, every one different (|x| < 3000: sum|x| 2^-15 ~ 165 > vad(data, 30): speech)."""
+    import torch
+    return [torch.randint(-3000, 3000, (server.streams_per_manager, CHUNK), dtype=torch.int16, device=device, generator=gen)
+            for _ in range(n_managers)]
+
+
+class HostFeed(object):
+    """Chunks start in pinned host memory (a ring of `pool` buffers stands for the capture side); per handle a copy stream
+    and two device buffers: the upload of a manager's chunk runs while the manager before it on the same handle computes."""
+
+    def __init__(self, server, pool=8):
+        import torch
+        self.server, dev, S = server, server.device, server.streams_per_manager
+        self.host = [torch.randint(-3000, 3000, (S, CHUNK), dtype=torch.int16).pin_memory() for _ in range(pool)]
+        H = len(server.models)
+        self.copy = [torch.cuda.Stream(device=dev) for _ in range(H)]
+        self.dbuf = [[torch.empty(S, CHUNK, dtype=torch.int16, device=dev) for _ in range(2)] for _ in range(H)]
+        self.ready = [[torch.cuda.Event() for _ in range(2)] for _ in range(H)]
+        self.freed = [[torch.cuda.Event() for _ in range(2)] for _ in range(H)]
+        self.turn = [0] * H
+        self.pending = [None] * H          # slot whose consumer has been queued and whose `freed` event is still to be recorded
+        self.bytes_per_chunk = S * CHUNK * 2
+        for h in range(H):
+            for e in self.freed[h]:
+                e.record(server.streams[h])
+
+    def chunk_of(self, p, k):
+        """Called with manager k's compute stream current, right before its feed is queued."""
+        import torch
+        h = self.server.handle_of(k)
+        compute = torch.cuda.current_stream(self.server.device)
+        if self.pending[h] is not None:            # the feed queued last on this handle has consumed that slot
+            self.freed[h][self.pending[h]].record(compute)
+        slot = self.turn[h] & 1
+        self.turn[h] += 1
+        with torch.cuda.stream(self.copy[h]):
+            self.copy[h].wait_event(self.freed[h][slot])
+            self.dbuf[h][slot].copy_(self.host[(p * 131 + k) % len(self.host)], non_blocking=True)
+            self.ready[h][slot].record(self.copy[h])
+        compute.wait_event(self.ready[h][slot])
+        self.pending[h] = slot
+        return self.dbuf[h][slot]
+
+
+def sustained_streams(device, precision="fp32", streams_per_manager=16384, handles=2, periods=40, host_fed=False,
+                      headroom=0.97, max_attempts=4, mem_fraction=0.80, n_mel=40, log=None):
+    """-> dict (see the module docstring).  `headroom`: the first attempt loads the period to this share of what the unpaced
+    calibration says fits; every attempt with a miss drops 3 % of the managers."""
+    import torch
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.serving import StreamServer, run_paced
+    say = log or (lambda *_: None)
+    cfg = get_config(precision=precision, n_mel=n_mel)
+    S = int(streams_per_manager)
+    torch.cuda.synchronize(device)
+    free_start = torch.cuda.mem_get_info(device)[0]
+    server = StreamServer(cfg, device=device, streams_per_manager=S, handles=handles)
+    gen = torch.Generator(device=device).manual_seed(20260)
+    feed = HostFeed(server) if host_fed else None
+    # -- calibration: a handful of managers, unpaced, a few periods -> seconds per manager-chunk with `handles` streams in flight
+    cal = max(2 * handles, 6)
+    server.resize(cal)
+    pcm = [] if host_fed else _pcm(server, cal, device, gen)
+    chunk_of = (feed.chunk_of if host_fed else (lambda p, k: pcm[k]))
+    torch.cuda.synchronize(device)
+    for p in range(2):
+        server.feed_period(lambda k: chunk_of(p, k))
+    server.wait()
+    t0 = time.perf_counter()
+    for p in range(4):
+        server.feed_period(lambda k: chunk_of(p, k))
+    server.wait()
+    per_manager_s = (time.perf_counter() - t0) / (4 * cal)
+    launches = server.launches_per_chunk()
+    # -- what fits: in time, and in memory (persistent state + the device-resident chunk of each manager)
+    free_now = torch.cuda.mem_get_info(device)[0]
+    per_manager_bytes = max(1.0, (free_start - free_now) / float(cal))          # measured, calibration population
+    m_time = max(1, int(PERIOD_S * headroom / per_manager_s))
+    m_mem = max(1, int(free_start * mem_fraction / per_manager_bytes))
+    M = min(m_time, m_mem)
+    say("%s%s: calibration %.3f ms per %d-stream chunk (%d handles) -> %d managers fit a period (memory: %d)"
+        % (precision, " host-fed" if host_fed else "", per_manager_s * 1e3, S, handles, m_time, m_mem))
+    attempts, best = [], None
+    for _ in range(max_attempts):
+        server.resize(M)
+        while len(pcm) < M and not host_fed:
+            pcm.extend(_pcm(server, min(32, M - len(pcm)), device, gen))
+        torch.cuda.synchronize(device)                     # the new chunks were generated on the default stream
+        server.feed_period(lambda k: chunk_of(0, k))       # one untimed period: every new manager has run once
+        server.wait()
+        used = free_start - torch.cuda.mem_get_info(device)[0]
+        res = run_paced(server, chunk_of, periods=periods, period_s=PERIOD_S)
+        res.update({"managers": M, "streams": M * S})
+        attempts.append({"streams": M * S, "deadline_misses": res["deadline_misses"], "compute_ms_p50": res["compute_ms_p50"],
+                         "compute_ms_max": res["compute_ms_max"]})
+        say("  %d managers = %d streams: p50 %.1f ms, p99 %.1f, max %.1f, misses %d" % (M, M * S, res["compute_ms_p50"],
+            res["compute_ms_p99"], res["compute_ms_max"], res["deadline_misses"]))
+        if res["deadline_misses"] == 0:
+            best = res
+            best["device_bytes_used"] = used
+            break
+        M = max(1, min(M - 1, int(M * 0.97)))
+    hits = int(server.hits().sum()) if best else None
+    out = {"precision": precision, "fed_from": "pinned host memory, copy stream per handle" if host_fed else "device-resident int16 PCM, one chunk per manager of its own",
+           "streams_per_manager": S, "handles_and_hip_streams": handles, "period_ms": PERIOD_S * 1e3, "periods": periods,
+           "seconds": periods * PERIOD_S, "calibration_ms_per_manager_chunk": per_manager_s * 1e3,
+           "limited_by": "memory" if m_mem < m_time else "time", "attempts": attempts}
+    if best is None:
+        out["sustained_streams"] = None
+        out["note"] = "no attempt ran without a deadline miss"
+    else:
+        N = best["streams"]
+        state_bytes = None
+        if not host_fed:
+            state_bytes = best["device_bytes_used"] / float(N) - CHUNK * 2
+        out.update({"sustained_streams": N, "managers": best["managers"], "deadline_misses": 0,
+                    "compute_ms_p50": best["compute_ms_p50"], "compute_ms_p99": best["compute_ms_p99"], "compute_ms_max": best["compute_ms_max"],
+                    "late_start_ms_max": best["late_start_ms_max"], "load_p50": best["load"],
+                    "native_calls_per_period": best["managers"], "kernel_launches_per_period": best["managers"] * launches,
+                    "kernel_launches_per_chunk": launches,
+                    "device_bytes_per_stream_total": best["device_bytes_used"] / float(N),
+                    "device_bytes_per_stream_state_carry_window": state_bytes,
+                    "device_GB_used": best["device_bytes_used"] / 1e9,
+                    "triggers_in_the_last_period": hits})
+        if host_fed:
+            out["pcie_GBps"] = best["managers"] * feed.bytes_per_chunk / (best["compute_ms_p50"] * 1e-3) / 1e9
+            out["pcie_GBps_needed_at_real_time"] = N * CHUNK * 2 / PERIOD_S / 1e9
+    server.close()
+    del pcm, feed
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--streams-per-manager", type=int, default=16384)
+    ap.add_argument("--handles", type=int, default=2)
+    ap.add_argument("--periods", type=int, default=40)
+    ap.add_argument("--n-mel", type=int, default=40)
+    ap.add_argument("--host-fed", action="store_true")
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    import torch
+    dev = torch.device("cuda", 0)
+    res = sustained_streams(dev, a.precision, a.streams_per_manager, a.handles, a.periods, a.host_fed, n_mel=a.n_mel,
+                            log=None if a.json else (lambda s: print(s, flush=True)))
+    if a.json:
+        print(json.dumps(res))
+    else:
+        print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

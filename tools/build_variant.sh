@@ -17,6 +17,8 @@ done
 C=$W/keyword_spotting_amd/csrc
 # the product's own Makefile (flags, per-file options) on the patched copy; include/ sits two levels above csrc there too
 mkdir -p $W/include && cp $ROOT/include/*.h $W/include/
-make -s -C $C -j8 OUT=$OUT/libkws_$NAME.so EXTRA="${FLAGS[*]}"
+# KWS_VARIANT_BUILD is defined HERE and nowhere else: csrc/kws_internal.h refuses an experiment switch without it, and
+# kws_version() of the result says "VARIANT BUILD" and which switches
+make -s -C $C -j8 OUT=$OUT/libkws_$NAME.so SPILL_CHECK= EXTRA="-DKWS_VARIANT_BUILD=1 ${FLAGS[*]}"
 rm -rf $W
 echo built $OUT/libkws_$NAME.so
