@@ -535,13 +535,20 @@ gru_stack_bf16_ls(const GruBf16Params p) {
                 for (int c = 0; c < KC0; ++c)
                     w0[j][q][c] = as_bf16x8(reinterpret_cast<const u32x4*>(p.w[0])[(((2 * w + j) * 3 + q) * KC0 + c) * 64 + lane]);
         // all loads first, the AGPR pins afterwards: a pin right behind its load makes the compiler wait for that load before it
-        // issues the next one (36 serial L2 round trips per launch)
+        // issues the next one (36 serial L2 round trips per launch).
+        // 2 x 3 x KC0 operands: 30 (KX0 = 1) fit the 32 operand slots of this wave's 128 AGPRs.  Of the 36 at KX0 = 2 the
+        // candidate's x-part (4) stays in VGPRs and goes through the builtin MFMA: pinned, the compiler kept them in VGPRs anyway
+        // and shuttled them into an AGPR (v_accvgpr_write) right in front of the inline-asm MFMA that reads it -- 56 copies per
+        // iteration and a VALU-write -> MFMA-read distance nobody checks (round 6: a re-scheduled variant of this kernel
+        // computed garbage that way; this one had been lucky).
+        constexpr bool kCxInVgpr = 2 * 3 * KC0 > 32;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
-                for (int c = 0; c < KC0; ++c) asm volatile("" : "+a"(w0[j][q][c]));
+                for (int c = 0; c < KC0; ++c)
+                    if (!(kCxInVgpr && q == 2 && c < KX0)) asm volatile("" : "+a"(w0[j][q][c]));
         asm volatile("s_nop 7" ::: "memory");
         // mel: wave w fetches streams 4w..4w+3 (one dwordx4 per lane), rounds to bf16, scatters into the B-operand image
         const int XQ = p.I / 4;
@@ -567,15 +574,21 @@ gru_stack_bf16_ls(const GruBf16Params p) {
                 const int o = (2 * w + j) * 4 + g;
                 r0[j] = bl[0 * 32 + o]; u0[j] = bl[1 * 32 + o]; c0[j] = bl[2 * 32 + o];
             }
+            if constexpr (kCxInVgpr) {
+#pragma unroll
+                for (int c = 0; c < KX0; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) c0[j] = mfma_bf16(w0[j][2][c], xB[c], c0[j]);
+            }
             mfma_prefence(r0[0], u0[0], r0[1], u0[1]);
-            mfma_prefence(c0[0], c0[1]);
+            if constexpr (!kCxInVgpr) mfma_prefence(c0[0], c0[1]);
 #pragma unroll
             for (int c = 0; c < KX0; ++c)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     KWS_MFMA_BF16_A(r0[j], w0[j][0][c], xB[c]);
                     KWS_MFMA_BF16_A(u0[j], w0[j][1][c], xB[c]);
-                    KWS_MFMA_BF16_A(c0[j], w0[j][2][c], xB[c]);
+                    if constexpr (!kCxInVgpr) KWS_MFMA_BF16_A(c0[j], w0[j][2][c], xB[c]);
                 }
 #pragma unroll
             for (int m = 0; m < 4; ++m)

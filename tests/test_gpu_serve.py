@@ -120,7 +120,9 @@ def test_managers_share_the_models_staging_block_and_own_only_their_state():
     # state 1024 + two carries 2 x 399 x 4 + summaries 15 x 36 + head/count 8 + restart 1 + hit 4 = 4769 B, plus what the
     # allocators round seven blocks per manager up to (2 MiB granules: up to ~0.9 KB per stream at this size); a manager that
     # kept its own chunk intermediates would add 34 frames x (160 + 24) B + masks = 6.3 KB per stream
-    assert 4700 <= per_stream <= 6200, per_stream
+    # (lower bound: what the library itself allocates -- carries 3192 + summaries 548; the manager's torch tensors may come out
+    # of blocks the caching allocator already holds)
+    assert 3700 <= per_stream <= 6200, per_stream
     assert m.scratch_stats()[1] == allocs0, "a manager of the same size must not regrow the handle's blocks"
     for mgr in more + [first]:
         mgr.close()

@@ -353,6 +353,8 @@ def test_a_stream_switch_is_ordered_on_the_device_and_does_not_drain_other_handl
     ma, mb = DeployModel(cfg, wa), DeployModel(cfg, wb)
     mb.reserve(bb, tb)
     ma.forward(mel_a[0], ma.zero_state(ba))              # A's scratch is sized before the race
+    st, pw = ma.zero_state(ba), ma.fresh_prev_word(ba)       # (filled on the default stream: synchronised before the side streams use them)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     started, box = threading.Event(), {}
     sb = torch.cuda.Stream()
@@ -360,8 +362,6 @@ def test_a_stream_switch_is_ordered_on_the_device_and_does_not_drain_other_handl
     t0 = time.perf_counter()
     th.start()
     assert started.wait(60)
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    st, pw = ma.zero_state(ba), ma.fresh_prev_word(ba)        # (allocated on the default stream while B runs: no sync here)
     ta0 = time.perf_counter()
     for k in range(24):
         with torch.cuda.stream((s1, s2)[k % 2]):
