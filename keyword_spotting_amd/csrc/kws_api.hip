@@ -98,6 +98,7 @@ struct kws_model {
     std::vector<size_t> f16_w;
     size_t f16_wfc = 0;
     int f16_kx0 = 0;
+    bool f16_generic = false;        // hidden != 128: the L2-streaming kernels (gru_f16x3_generic.hip)
     // int8 ("octbit") variant: per quantised layer the packed int16 couples + 127*colsum, and the projection
     struct OctLayer { bool quantised = false; size_t wg = 0, wc = 0, b127 = 0; float scale_g = 0.f, scale_c = 0.f; };
     std::vector<OctLayer> oct;
@@ -153,7 +154,7 @@ struct kws_model {
     std::vector<int32_t> launches;
     // kernel the last kws_step launched per profiling slot, as a small tag: the name is only formatted when somebody asks
     // (kws_last_launch, kws_selftest) -- not on the launch path, where a 22-frame call is ~100 us of device time
-    enum LaunchFamily : uint8_t { kNone = 0, kBf16Stack, kF16x3, kPipelined, kOctbit, kOctbitFc, kResident, kGeneric };
+    enum LaunchFamily : uint8_t { kNone = 0, kBf16Stack, kF16x3, kPipelined, kOctbit, kOctbitFc, kResident, kGeneric, kF16x3Generic, kF16x3Pipelined };
     struct LaunchTag { uint8_t family = kNone, kx = 0, first = 0, last = 0, window = 0; };
     LaunchTag launch_tag[8];
     std::string launch_name(int slot) const {
@@ -164,6 +165,8 @@ struct kws_model {
             case kBf16Stack: break;
             case kF16x3: snprintf(nm, sizeof(nm), "gru_layer_f16x3<%d, %s, %s>", t.kx, t.first ? "true" : "false", t.last ? "true" : "false"); break;
             case kPipelined: snprintf(nm, sizeof(nm), "gru_stack_generic_pipelined<%d> (all %d layers, one launch)", t.kx, cfg.num_layers); break;
+            case kF16x3Generic: snprintf(nm, sizeof(nm), "gru_layer_f16x3_generic<%d, %s, %s>", t.kx, t.first ? "true" : "false", t.last ? "true" : "false"); break;
+            case kF16x3Pipelined: snprintf(nm, sizeof(nm), "gru_stack_f16x3_pipelined<%d> (all %d layers, one launch)", t.kx, cfg.num_layers); break;
             case kOctbit: snprintf(nm, sizeof(nm), "gru_layer_octbit_kernel"); break;
             case kOctbitFc: snprintf(nm, sizeof(nm), "gru_layer_octbit_kernel + octbit_fc_kernel"); break;
             case kResident: snprintf(nm, sizeof(nm), "gru_layer_resident<%d, %s, %s>", t.kx, t.first ? "true" : "false", t.last ? "true" : "false"); break;
@@ -272,8 +275,9 @@ bool config_ok(const kws_config* c, int* code) {
         return false;
     }
     if (c->precision != KWS_FP32 && c->precision != KWS_BF16 && c->precision != KWS_INT8 && c->precision != KWS_F16X3) { *code = fail(KWS_ERR_INVALID_ARGUMENT, "unknown precision %d", c->precision); return false; }
-    if (c->precision == KWS_F16X3 && !kws::gru_f16x3_supported(c->hidden, c->n_mel)) {
-        *code = fail(KWS_ERR_UNSUPPORTED, "f16x3 path needs hidden=128 and n_mel%%4==0, 4..64; got hidden=%d n_mel=%d", c->hidden, c->n_mel);
+    if (c->precision == KWS_F16X3 && !kws::gru_f16x3_supported(c->hidden, c->n_mel) && !kws::gru_f16x3_generic_supported(c->hidden, c->n_mel)) {
+        *code = fail(KWS_ERR_UNSUPPORTED, "f16x3 path needs hidden=128 (register-resident kernels) or 256 (weights streamed from L2) and n_mel%%4==0, 4..64; "
+                     "got hidden=%d n_mel=%d", c->hidden, c->n_mel);
         return false;
     }
     if (c->precision == KWS_BF16 && !kws::gru_bf16_supported(c->hidden, c->n_mel, c->num_layers)) {
@@ -518,14 +522,18 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
             if (!wq_) { delete m; return KWS_ERR_UNSUPPORTED; }
         }
         int in_l = cfg->n_mel;
-        m->f16_kx0 = (cfg->n_mel + 31) / 32;
+        // hidden = 128: the register-resident kernels (gru_f16x3.hip); otherwise the streaming ones (gru_f16x3_generic.hip), whose
+        // phases come in row pairs: the first layer's x chunks are padded to an even count (zero operands)
+        m->f16_generic = !kws::gru_f16x3_supported(H, cfg->n_mel);
+        m->f16_kx0 = m->f16_generic ? 2 * ((cfg->n_mel + 63) / 64) : (cfg->n_mel + 31) / 32;
+        const int HCh = H / 32;                    // 32-wide chunks of a hidden vector
         for (int l = 0; l < cfg->num_layers; ++l) {
             const float* Wg = q;
             const float* Wc = Wg + (size_t)(in_l + H) * 2 * H + 2 * H;
-            const int kx = l == 0 ? m->f16_kx0 : 4, kc = kx + 4;
-            m->f16_w.push_back(reserve((size_t)8 * 3 * kc * 2 * 64 * 4));
+            const int kx = l == 0 ? m->f16_kx0 : HCh, kc = kx + HCh;
+            m->f16_w.push_back(reserve((size_t)NT * 3 * kc * 2 * 64 * 4));
             uint16_t* dst = reinterpret_cast<uint16_t*>(&host[m->f16_w[l]]);
-            for (int n = 0; n < 8; ++n)
+            for (int n = 0; n < NT; ++n)
                 for (int gq = 0; gq < 3; ++gq)
                     for (int c = 0; c < kc; ++c)
                         for (int lane = 0; lane < 64; ++lane)
@@ -553,9 +561,9 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
             q = Wc + (size_t)(in_l + H) * H + H;
             in_l = H;
         }
-        m->f16_wfc = reserve((size_t)4 * 2 * 64 * 4);
+        m->f16_wfc = reserve((size_t)HCh * 2 * 64 * 4);
         uint16_t* dst = reinterpret_cast<uint16_t*>(&host[m->f16_wfc]);
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < HCh; ++c)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
                     const int g = lane >> 4, i = lane & 15;
@@ -716,7 +724,8 @@ static bool pipeline_eligible(kws_handle h, int B) {
     // B <= 2048; L=4, B=1024: 2.2x; select it with KWS_KERNEL_GENERIC): the two kernel families round differently in
     // the last bit, and a stream's result must not depend on how many neighbours it is batched or sharded with.
     if (h->pipe_disabled) return false;
-    if (h->cfg.precision != KWS_FP32 || h->cfg.num_layers < 2 || h->kernel_kind == KWS_KERNEL_RESIDENT) return false;
+    const bool f16_streaming = h->cfg.precision == KWS_F16X3 && h->f16_generic;      // gru_stack_f16x3_pipelined
+    if ((h->cfg.precision != KWS_FP32 && !f16_streaming) || h->cfg.num_layers < 2 || h->kernel_kind == KWS_KERNEL_RESIDENT) return false;
     for (const auto& L : h->layers)
         if (h->kernel_kind == KWS_KERNEL_AUTO && L.resident_ok) return false;
     const long long groups = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup;
@@ -1002,7 +1011,7 @@ static bool step_takes_window(kws_handle h, int B, int T, int window_chunks) {
     // window_inc_kernel behind the stack)
     if ((B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup > (h->num_cus > 0 ? h->num_cus : 256)) return false;
     if (c.precision == KWS_BF16) return kws::gru_stack_bf16_takes_window(h->bf_kx0, c.num_layers);
-    if (c.precision == KWS_F16X3) return true;
+    if (c.precision == KWS_F16X3) return !h->f16_generic;
     if (c.precision != KWS_FP32 || pipeline_eligible(h, B) || overlap_eligible(h, B, T)) return false;
     const LayerDev& Ld = h->layers[c.num_layers - 1];
     const bool resident = h->kernel_kind == KWS_KERNEL_RESIDENT || (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok);
@@ -1091,9 +1100,9 @@ static int step_body(kws_handle h, const float* mel, const float* state_in, floa
         return KWS_OK;
     }
     if (!mel) return fail(KWS_ERR_INVALID_ARGUMENT, "mel is null");
-    if (c.precision != KWS_BF16 && c.precision != KWS_F16X3) {
+    if (c.precision != KWS_BF16 && (c.precision != KWS_F16X3 || h->f16_generic)) {
         // the streaming kernels address a group's seam (T x H/16 KiB) through buffer instructions with 32-bit offsets
-        bool streaming = false;
+        bool streaming = c.precision == KWS_F16X3;
         for (const auto& Ld : h->layers)
             streaming |= !(h->kernel_kind == KWS_KERNEL_RESIDENT || (h->kernel_kind == KWS_KERNEL_AUTO && Ld.resident_ok));
         if (streaming && (long long)T * (H / 16) >= (1LL << 21))
@@ -1140,6 +1149,14 @@ static int step_body(kws_handle h, const float* mel, const float* state_in, floa
         // one launch per layer; the seams (same size as the fp32 ones) hold the layer outputs already split into fp16 pairs
         int rc = ensure_scratch(h, B, T);
         if (rc != KWS_OK) return rc;
+        // hidden = 256: weights streamed from L2; all L x groups workgroups in ONE layer-pipelined grid when they fit the chip
+        const bool f16_pipelined = h->f16_generic && pipeline_eligible(h, B);
+        kws::GruF16StackParams fsp;
+        if (f16_pipelined) {
+            KWS_HIP(hipMemsetAsync(h->pipe_ready, 0, (size_t)L * h->pipe_groups * sizeof(int), st));
+            memset(&fsp, 0, sizeof(fsp));
+            fsp.L = L; fsp.G = (B + kws::kStreamsPerGroup - 1) / kws::kStreamsPerGroup; fsp.xcd_affine = (8 % L == 0) ? 1 : 0;
+        }
         for (int l = 0; l < L; ++l) {
             const bool first = l == 0, last = l == L - 1;
             kws::GruF16Params fp;
@@ -1159,6 +1176,14 @@ static int step_body(kws_handle h, const float* mel, const float* state_in, floa
             fp.epi.B = B; fp.epi.T = T; fp.epi.C = c.num_classes;
             if (wt && last) fp.epi.win = *wt;
             fp.B = B; fp.T = T; fp.I = h->layers[l].in_dim;
+            if (f16_pipelined) {
+                fp.epi.ready_in = first ? nullptr : h->pipe_ready + (size_t)(l - 1) * h->pipe_groups;
+                fp.epi.ready_out = last ? nullptr : h->pipe_ready + (size_t)l * h->pipe_groups;
+                fp.epi.pipe_error = h->pipe_error_dev;
+                fsp.layer[l] = fp;
+                h->launch_tag[l] = {};
+                if (!last) continue;
+            }
             hipEvent_t ea = nullptr, eb = nullptr;
             if (h->profiling) {
                 for (hipEvent_t* ev : {&ea, &eb}) {
@@ -1167,9 +1192,20 @@ static int step_body(kws_handle h, const float* mel, const float* state_in, floa
                 }
                 KWS_HIP(hipEventRecord(ea, st));
             }
-            hipError_t e = kws::launch_gru_layer_f16x3(fp, first, last, st);
-            if (e != hipSuccess) return hip_fail(e, "launch gru_layer_f16x3");
-            h->launch_tag[l] = {kws_model::kF16x3, (uint8_t)(first ? h->f16_kx0 : 4), first, last, (uint8_t)(wt != nullptr && last)};
+            hipError_t e;
+            if (f16_pipelined) {
+                e = kws::launch_gru_stack_f16x3_pipelined(fsp, H, st);        // timed as the last layer's slot
+                if (e != hipSuccess) return hip_fail(e, "launch gru_stack_f16x3_pipelined");
+                h->launch_tag[l] = {kws_model::kF16x3Pipelined, (uint8_t)(H / 64), 0, 0};
+            } else if (h->f16_generic) {
+                e = kws::launch_gru_layer_f16x3_generic(fp, H, first, last, st);
+                if (e != hipSuccess) return hip_fail(e, "launch gru_layer_f16x3_generic");
+                h->launch_tag[l] = {kws_model::kF16x3Generic, (uint8_t)(H / 64), first, last};
+            } else {
+                e = kws::launch_gru_layer_f16x3(fp, first, last, st);
+                if (e != hipSuccess) return hip_fail(e, "launch gru_layer_f16x3");
+                h->launch_tag[l] = {kws_model::kF16x3, (uint8_t)(first ? h->f16_kx0 : 4), first, last, (uint8_t)(wt != nullptr && last)};
+            }
             if (h->profiling) {
                 KWS_HIP(hipEventRecord(eb, st));
                 h->pending.push_back({l, ea, eb});

@@ -175,6 +175,19 @@ struct GruF16Params {
     GruLayerParams epi;     // LAST: logits / softmax / tokens / prev_word / thresholds for the epilogue
     int B, T, I;
 };
+// ... for the shapes the resident kernels do not cover (hidden = 256: BASELINE configs[4]), weights streamed from L2 every frame
+// (gru_f16x3_generic.hip): one layer per launch, or all L x G workgroups in one layer-pipelined grid.  Tables as above with
+// H/16 tiles, H/32 hidden chunks and the first layer's x chunks padded to an even count; the pipelined launch takes ready_in /
+// ready_out / pipe_error from p.epi.
+struct GruF16StackParams {
+    GruF16Params layer[8];
+    int L, G;
+    int xcd_affine;
+};
+static_assert(sizeof(GruF16StackParams) <= 4096, "kernel arguments");
+bool gru_f16x3_generic_supported(int hidden, int n_mel);
+hipError_t launch_gru_layer_f16x3_generic(const GruF16Params& p, int hidden, bool first, bool last, hipStream_t st);
+hipError_t launch_gru_stack_f16x3_pipelined(const GruF16StackParams& sp, int hidden, hipStream_t st);
 bool gru_f16x3_supported(int hidden, int n_mel);
 hipError_t launch_gru_layer_f16x3(const GruF16Params& p, bool first, bool last, hipStream_t st);    // last && p.epi.win.tab: with the window tail
 bool gru_f16x3_vgpr_form();                                 // gru_f16x3.hip built with -mllvm -amdgpu-mfma-vgpr-form=1 (csrc/Makefile)

@@ -121,6 +121,38 @@ def test_stress_config_full_size_against_the_c_oracle(oracle_c):
     assert torch.equal(seq["logits"][:b], whole["logits"]) and torch.equal(seq["state"][:, :b], whole["state"])
 
 
+def test_stress_config_full_size_f16x3_against_the_c_oracle(oracle_c):
+    """configs[4] at fp32 tolerance on the fp16 matrix pipe: the weights of every h = 256 layer (1.5 MiB as (hi, lo) fp16 pairs)
+    streamed from L2 each frame, 64 groups x 4 layers in one layer-pipelined launch (gru_stack_f16x3_pipelined<4>)."""
+    w = G.random_weights(60, 256, 4, 6, seed=173)
+    b, t = 1024, 300
+    mel = _mel(b, t, 60, 174)
+    m = _model(n_mel=60, hidden_size=256, num_layers=4, weights=w, precision="f16x3")
+    whole = m.forward(mel, m.zero_state(b))
+    m.status()
+    assert m.kernel_names()[-1].startswith("gru_stack_f16x3_pipelined<4>")
+    pick = [0, 1, 15, 16, 17, 511, 512, 1007, 1008, 1022, 1023] + list(range(40, 1000, 48))
+    c_l, _, c_s = oracle_c.gru_forward((60, 256, 4, 6, 0, -1.0), G.weights_to_blob(w), mel[pick].cpu().numpy(),
+                                       np.zeros((4, len(pick), 256), np.float32), threads=8)
+    el = np.abs(whole["logits"][pick].cpu().numpy() - c_l)
+    es = np.abs(whole["state"][:, pick].cpu().numpy() - c_s)
+    print("configs[4] f16x3 B=1024 T=300, %d streams vs C oracle: logits max %.2e | state max %.2e" % (len(pick), el.max(), es.max()))
+    assert el.max() < 1e-4 and es.max() < 1e-4
+    part = m.forward(mel[pick].contiguous(), m.zero_state(len(pick)))
+    assert torch.equal(part["logits"], whole["logits"][pick]) and torch.equal(part["state"], whole["state"][:, pick])
+    state, pos = m.zero_state(b), 0
+    for n in (150, 22, 128):
+        lg, state = m.step(mel[:, pos:pos + n].contiguous(), state)
+        assert torch.equal(lg, whole["logits"][:, pos:pos + n])
+        pos += n
+    assert torch.equal(state, whole["state"])
+    # 4096 streams of the same model (256 groups x 4 layers > CUs: layer-by-layer launches) agree with the pipelined launch bit
+    # for bit on the shared streams
+    big = torch.cat([mel, _mel(3072, t, 60, 175)], 0)
+    seq = m.forward(big, m.zero_state(4096), want_softmax=False)
+    assert torch.equal(seq["logits"][:b], whole["logits"]) and torch.equal(seq["state"][:, :b], whole["state"])
+
+
 def test_reserved_scratch_is_never_regrown_and_layouts_can_alternate():
     """kws_reserve sizes the one scratch block for whichever launch layout a shape takes; alternating streaming-hop and
     long calls (sequential <-> layers overlapped on HIP streams) afterwards neither reallocates nor changes a bit."""

@@ -29,7 +29,8 @@ def _cfg_tuple(shape, use_relu=0, clip=-1.0):
 
 SHAPES = {"A": (40, 128, 2, 6), "B": (60, 128, 2, 6), "C": (60, 256, 4, 6),
           "D": (64, 128, 2, 6), "E": (32, 128, 1, 6), "F": (48, 128, 3, 6),     # the other resident front-end widths
-          "G": (12, 128, 4, 5)}                                                 # f16x3 only: narrow input, four layers, C = 5
+          "G": (12, 128, 4, 5),                                                 # f16x3 only: narrow input, four layers, C = 5
+          "H": (24, 256, 2, 6)}                                                 # f16x3 streaming kernels: one (padded) input chunk, two layers
 
 
 @pytest.mark.parametrize("name,kernel,batch,frames", [
@@ -38,7 +39,9 @@ SHAPES = {"A": (40, 128, 2, 6), "B": (60, 128, 2, 6), "C": (60, 256, 4, 6),
     ("C", "generic", 20, 12), ("C", "auto", 3, 40),
     ("D", "resident", 19, 30), ("E", "resident", 35, 26), ("F", "resident", 8, 41),
     ("A", "f16x3", 37, 50), ("A", "f16x3", 1, 300), ("A", "f16x3", 16, 1), ("A", "f16x3", 33, 7), ("B", "f16x3", 20, 23),
-    ("D", "f16x3", 19, 30), ("E", "f16x3", 35, 26), ("F", "f16x3", 8, 41), ("G", "f16x3", 21, 19)])
+    ("D", "f16x3", 19, 30), ("E", "f16x3", 35, 26), ("F", "f16x3", 8, 41), ("G", "f16x3", 21, 19),
+    # hidden = 256: the L2-streaming f16x3 kernels (gru_f16x3_generic.hip), layer-pipelined at these sizes
+    ("C", "f16x3", 20, 12), ("C", "f16x3", 3, 40), ("C", "f16x3", 1, 1), ("H", "f16x3", 37, 9)])
 def test_logits_state_softmax_match_oracle(oracle_c, name, kernel, batch, frames):
     shape = SHAPES[name]
     i, h, l, c = shape
@@ -311,7 +314,7 @@ def test_f16x3_preconditions_and_its_distance_from_the_fp32_kernels():
     ok["bfc"][2] = -300.0
     _model(SHAPES["A"], ok, "f16x3")
     with pytest.raises(_lib.UnsupportedError):
-        _model(SHAPES["C"], G.init_weights(60, 256, 4, 6), "f16x3")   # hidden 256
+        _model((40, 64, 2, 6), G.init_weights(40, 64, 2, 6), "f16x3")   # hidden 64: neither the resident (128) nor the streaming (256) kernels
     mel = torch.from_numpy(G.synthetic_mel(64, 300, 40, seed=83))
     a, f = _model(SHAPES["A"], w, "resident"), _model(SHAPES["A"], w, "f16x3")
     ra = a.forward(mel, a.zero_state(64), prev_word=a.fresh_prev_word(64))
@@ -321,3 +324,50 @@ def test_f16x3_preconditions_and_its_distance_from_the_fp32_kernels():
           % (d, int((ra["tokens"] != rf["tokens"]).sum()), ra["tokens"].numel()))
     assert d < 2e-5                                               # not bit-identical (another summation order), fp32-rounding close
     assert f.kernel_names() == ["gru_layer_f16x3<2, true, false>", "gru_layer_f16x3<4, false, true>"]
+
+
+def test_f16x3_streaming_kernels_masks_chunks_and_launch_layouts():
+    """hidden = 256 at fp32 tolerance on the fp16 matrix pipe (gru_f16x3_generic.hip): sequence lengths and reset masks as
+    dynamic_rnn / clean_state define them, chunked calls == one call bit for bit, and the two launch layouts -- all layers in
+    one layer-pipelined grid (L x groups <= CUs) and one launch per layer -- agree bit for bit on shared streams."""
+    shape = SHAPES["C"]
+    i, h, l, c = shape
+    w = G.random_weights(i, h, l, c, seed=91)
+    b, t = 23, 30
+    rng = np.random.default_rng(92)
+    mel = G.synthetic_mel(b, t, i, seed=93)
+    st0 = (0.5 * rng.standard_normal((l, b, h))).astype(np.float32)
+    lens = rng.integers(0, t + 1, b).astype(np.int32)
+    lens[0], lens[1] = 0, t
+    reset = (rng.random(b) < 0.3).astype(np.uint8)
+    st_eff = st0.copy()
+    st_eff[:, reset != 0] = 0
+    want_l, want_s = G.gru_forward(w, mel, st_eff, seq_len=lens, dtype=np.float64)
+    m = _model(shape, w, "f16x3")
+    r = m.forward(torch.from_numpy(mel), torch.from_numpy(st0), seq_len=torch.from_numpy(lens), reset_mask=torch.from_numpy(reset),
+                  prev_word=m.fresh_prev_word(b))
+    assert m.kernel_names()[-1].startswith("gru_stack_f16x3_pipelined<4>")
+    got_l, got_s = r["logits"].cpu().numpy(), r["state"].cpu().numpy()
+    assert np.abs(got_l - want_l).max() < TOL and np.abs(got_s - want_s).max() < TOL
+    bias_row = r["logits"][0, 0].clone()
+    for k in range(b):                                         # the zero-output row past seq_len: logits = bfc, bit for bit
+        if lens[k] < t:
+            assert torch.equal(r["logits"][k, int(lens[k]):], bias_row.expand(t - int(lens[k]), -1))
+    # chunked == one shot
+    x = torch.from_numpy(mel).cuda()
+    whole = m.forward(x, torch.from_numpy(st0))
+    state, pos, parts = torch.from_numpy(st0).cuda(), 0, []
+    for n in (7, 1, 16, 6):
+        rr = m.forward(x[:, pos:pos + n].contiguous(), state)
+        parts.append(rr["logits"]); state = rr["state"]; pos += n
+    assert torch.equal(torch.cat(parts, 1), whole["logits"]) and torch.equal(state, whole["state"])
+    # more groups than the pipelined grid takes (L x groups > CUs): one launch per layer, same bits on the shared streams
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    big_b = 16 * (cus // l + 1)
+    big = torch.from_numpy(G.synthetic_mel(big_b, 6, i, seed=94)).cuda()
+    seq = m.forward(big, m.zero_state(big_b))
+    assert m.kernel_names() == ["gru_layer_f16x3_generic<4, true, false>"] + ["gru_layer_f16x3_generic<4, false, false>"] * (l - 2) + \
+        ["gru_layer_f16x3_generic<4, false, true>"]
+    pipe = m.forward(big[:48].contiguous(), m.zero_state(48))
+    assert torch.equal(pipe["logits"], seq["logits"][:48]) and torch.equal(pipe["state"], seq["state"][:, :48])
+    m.status()

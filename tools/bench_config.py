@@ -9,8 +9,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n-mel", type=int, default=60); ap.add_argument("--hidden", type=int, default=256)
 ap.add_argument("--layers", type=int, default=4); ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--frames", type=int, default=300); ap.add_argument("--kernel", default="auto")
+ap.add_argument("--precision", default="fp32")
 a = ap.parse_args()
-cfg = get_config(n_mel=a.n_mel, hidden_size=a.hidden, num_layers=a.layers)
+cfg = get_config(n_mel=a.n_mel, hidden_size=a.hidden, num_layers=a.layers, precision=a.precision)
 m = DeployModel(cfg, weights.init_weights(cfg), kernel=a.kernel)
 mel = torch.randn(a.batch, a.frames, a.n_mel, device="cuda").abs() * 2
 st = m.zero_state(a.batch)
@@ -20,5 +21,5 @@ n = 10
 for _ in range(n): m.forward(mel, st, state_out=st)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 macs = sum(((a.n_mel if l == 0 else a.hidden) + a.hidden) * 3 * a.hidden for l in range(a.layers)) + a.hidden * 6
-print("I=%d H=%d L=%d B=%d T=%d kernel=%s: %.3f ms/step  %.1f M frames/s  %.1f TFLOP/s" % (a.n_mel, a.hidden, a.layers, a.batch, a.frames, a.kernel,
-      dt * 1e3, a.batch * a.frames / dt / 1e6, 2 * macs * a.batch * a.frames / dt / 1e12))
+print("I=%d H=%d L=%d B=%d T=%d kernel=%s %s [%s]: %.3f ms/step  %.1f M frames/s  %.1f TFLOP/s (algorithmic)" % (a.n_mel, a.hidden, a.layers, a.batch, a.frames, a.kernel,
+      a.precision, m.kernel_names()[-1], dt * 1e3, a.batch * a.frames / dt / 1e6, 2 * macs * a.batch * a.frames / dt / 1e12))
