@@ -354,6 +354,53 @@ def secondary_lines(device):
         out["detector.py loop, PCM in -> trigger out, %s, %d streams x 225 ms chunks (VAD, front-end, GRU, window)" % (prec, B)] = entry
         mgr.close()
         m.close()
+    # the int8 ("octbit") graph through the same loop (no window tail in its last layer: window_inc_kernel follows the stack)
+    cfg = get_config(precision="int8")
+    m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+    fe, mgr = MelFrontend(cfg), StreamManager(m, B)
+    k8 = [0]
+    def chunk8():
+        mgr.feed_pcm(pcm[k8[0] % 4], fe)
+        k8[0] += 1
+    for _ in range(3):
+        chunk8()
+    dt = timed(chunk8, 100)
+    names = m.kernel_names()
+    out["detector.py loop, PCM in -> trigger out, int8, %d streams x 225 ms chunks (VAD, front-end, GRU, window)" % B] = {
+        "realtime_streams": B * 0.225 / dt, "ms_per_chunk": dt * 1e3,
+        "kernel_launches_per_chunk": 5,       # gate + front-end | fp32 layer 0 | int8 layer 1 (leaves the projection's activation ranges) | int8 projection | window step
+        "kernels": names, "window_step": "incremental, window_inc_kernel behind the stack"}
+    mgr.close()
+    m.close()
+    del pcm
+    # the reference's SHIPPED default front-end width: n_mel = 60 (config/rnn_config.py:63; BASELINE's 40 is README.md:17) --
+    # resident first layer with 15 x-part k-chunks; 4096 x 300 and the 22-frame streaming hop, fp32 and f16x3
+    flop60 = [2 * (60 + 128) * 3 * 128, 2 * ((128 + 128) * 3 * 128 + 128 * 6)]
+    for prec in ("fp32", "f16x3"):
+        cfg = get_config(precision=prec, n_mel=60)
+        m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+        entry = {}
+        for t_ in (T, 22):
+            mel = (torch.randn(B, t_, 60, device=device).abs() * 2).contiguous()
+            st, pw = m.zero_state(B), m.fresh_prev_word(B)
+            o_ = {"logits": torch.empty(B, t_, cfg.num_classes, device=device), "softmax": torch.empty(B, t_, cfg.num_classes, device=device),
+                  "tokens": torch.empty(B, t_, dtype=torch.int8, device=device)}
+            m.reserve(B, t_)
+            for _ in range(3):
+                m.forward(mel, st, prev_word=pw, state_out=st, out=o_)
+            m.set_profiling(True)
+            m.kernel_times()
+            dt = timed(lambda: m.forward(mel, st, prev_word=pw, state_out=st, out=o_), 10 if t_ == T else 64)
+            kt = m.kernel_times()
+            m.set_profiling(False)
+            per = [k_[0] / max(k_[1], 1) for k_ in kt]
+            mult, peak = (3, 2500.0) if prec == "f16x3" else (1, PEAK_FP32_TFLOPS)
+            entry["%d frames per call" % t_] = {
+                "mel_frames_per_s": B * t_ / dt, "ms_per_call": dt * 1e3, "kernels": m.kernel_names(), "per_layer_ms": per,
+                "frac_per_layer": [mult * flop60[l] * B * t_ / (per[l] * 1e-3) / 1e12 / peak for l in range(2)],
+                "peak_tflops": peak, "flops_counted": "issued (3 MFMAs per product)" if mult == 3 else "algorithmic"}
+        out["the reference's shipped default n_mel=60 (config/rnn_config.py:63), 2xGRU h=128, %s, %d streams" % (prec, B)] = entry
+        m.close()
     cfg = get_config(n_mel=60, hidden_size=256, num_layers=4)
     m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
     mel = (torch.randn(1024, T, 60, device=device).abs() * 2).contiguous()
@@ -361,11 +408,52 @@ def secondary_lines(device):
     dt = timed(lambda: m.forward(mel, st, state_out=st), 5)
     macs = sum(((60 if l == 0 else 256) + 256) * 3 * 256 for l in range(4)) + 256 * 6
     tf = 2 * macs * 1024 * T / dt / 1e12
+    dt_fp32_c4 = dt
     out["configs[4] 4xGRU h=256 n_mel=60, 1024 streams x %d frames, fp32 (layer-pipelined launch)" % T] = {
         "mel_frames_per_s": 1024 * T / dt, "ms_per_step": dt * 1e3, "tflops": tf, "frac": tf / PEAK_FP32_TFLOPS,
         "roofline": {"bound": "mfma", "kernel": "gru_stack_generic_pipelined<4>", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
                      "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS}}
     m.close()
+    # ... and at fp32 tolerance on the fp16 matrix pipe: every layer's (hi, lo) fp16 operand pairs (1.5 MiB at h = 256, the size of the
+    # fp32 weights) streamed from L2 each frame, three MFMAs per pair.  What bounds it is the L2 -> CU stream, not the matrix pipe:
+    # bytes = table bytes of all layers x groups x frames (tools/ubench/l2_stream_f16x3.hip: 12.7-13.8 us per frame at best)
+    cfg = get_config(n_mel=60, hidden_size=256, num_layers=4, precision="f16x3")
+    m = DeployModel(cfg, weights.init_weights(cfg, seed=0), device=device)
+    acc_ref = DeployModel(get_config(n_mel=60, hidden_size=256, num_layers=4), weights.init_weights(cfg, seed=0), device=device)
+    am_ = (torch.randn(64, T, 60, device=device).abs() * 2).contiguous()
+    ra_ = acc_ref.forward(am_, acc_ref.zero_state(64), prev_word=acc_ref.fresh_prev_word(64))
+    rf_ = m.forward(am_, m.zero_state(64), prev_word=m.fresh_prev_word(64))
+    acc_ref.close()
+    dt = timed(lambda: m.forward(mel, st, state_out=st), 8)
+    tf = 2 * macs * 1024 * T / dt / 1e12
+    l2_bytes = (16 * 3 * (2 + 8) + 3 * 16 * 3 * 16) * 2 * 1024 * 64 * T          # operands of 2 x 1 KiB: layer 0 has 2 + 8 chunks, layers 1-3 8 + 8
+    out["configs[4] 4xGRU h=256 n_mel=60, 1024 streams x %d frames, f16x3 (fp32 tolerance; weights streamed from L2, layer-pipelined launch)" % T] = {
+        "mel_frames_per_s": 1024 * T / dt, "ms_per_step": dt * 1e3, "speedup_vs_the_fp32_kernels": dt_fp32_c4 / dt,
+        "algorithmic_tflops": tf, "algorithmic_tflops_over_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS,
+        "accuracy": {"vs": "fp32 kernels, same weights and mel, 64 streams x %d frames" % T,
+                     "max_abs_dlogit": float((rf_["logits"] - ra_["logits"]).abs().max()),
+                     "streams_with_identical_token_sequence": float((rf_["tokens"] == ra_["tokens"]).all(1).float().mean())},
+        "roofline": {"bound": "l2-stream", "kernel": m.kernel_names()[-1], "achieved": l2_bytes / dt / 1e12, "peak": 34.5, "unit": "TB/s out of the eight L2s",
+                     "frac": l2_bytes / dt / 1e12 / 34.5, "bytes_per_step": l2_bytes,
+                     "mfma": {"issued_tflops": 3 * tf, "peak": 2500.0, "frac": 3 * tf / 2500.0},
+                     "floor_us_per_frame_microbenchmark": "12.7-13.8 (tools/ubench/l2_stream_f16x3.hip, profiles/r6_l2_stream_ubench.txt)",
+                     "us_per_frame": dt * 1e6 / (T + 3)}}
+    m.close()
+    del mel, st
+    torch.cuda.empty_cache()
+    # BASELINE.json's metric as worded -- "real-time audio streams SUSTAINED": N = M x 16384 DISTINCT streams resident (state, sample
+    # carry, decode window, and a 225 ms int16 chunk of its own per manager), every manager fed one chunk per 225 ms period for 40
+    # periods (9 s) in real time, M native calls per period in turn on 2 HIP streams / model handles; the largest N with ZERO
+    # deadline misses (tools/bench_serve.py; detector.py:119,158-209).  The host-fed variant starts every chunk in pinned host memory.
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_serve
+        for prec in ("fp32", "f16x3", "bf16"):
+            out["sustained real-time, N distinct streams, %s" % prec] = bench_serve.sustained_streams(device, prec, periods=40, max_attempts=2)
+        out["sustained real-time, N distinct streams, fp32, host-fed (pinned int16 over PCIe, copy streams overlapped)"] = \
+            bench_serve.sustained_streams(device, "fp32", periods=40, max_attempts=2, host_fed=True)
+    except Exception as exc:
+        out["sustained real-time, N distinct streams"] = {"error": repr(exc)}
     return out
 
 
@@ -712,6 +800,7 @@ def main(argv=None, model_factory=None):
             # the headline above is K steps (tens of milliseconds): the same step() for >= 10 s tells whether it holds under
             # sustained power/thermal load (reported beside it, never as `value`)
             line["sustained"] = sustained_run(step, device_sync, B * T, args.sustain_seconds)
+            line["value_sustained_10s"] = line["sustained"]["mel_frames_per_s"]         # the same step for >= 10 s, next to the K-step `value`
             try:
                 line["secondary"] = secondary_lines(device)
                 for k_, e_ in line["secondary"].items():

@@ -60,7 +60,7 @@ __device__ __forceinline__ void g_split8(const f32x4& a, const f32x4& b, gu32x4&
 size_t gru_f16x3_generic_lds_bytes(int hidden, bool last) {
     const size_t hc = hidden / 32;
     size_t n = 3 * hc * 2 * 64 * 16;              // hb, rhb, xsb (the first layer's input needs <= 2 chunks of xsb)
-    n += (size_t)3 * hidden * 4 + 16 * 4;         // biases + class bias
+    n += (size_t)3 * hidden * 4 + 16 * 4 + 16;    // biases + class bias + the pipelined launch's "next frame is there" flag
     if (last) n += kEpilogueLdsBytes;
     return n;
 }
@@ -68,7 +68,7 @@ size_t gru_f16x3_generic_lds_bytes(int hidden, bool last) {
 // TPW: tiles per wave, H = 64 TPW (2: h = 128, 4: h = 256).  PIPE: the layer-pipelined launch.
 template <int TPW, bool FIRST, bool LAST, bool PIPE>
 __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, const int group) {
-    constexpr int NT = 4 * TPW, H = 64 * TPW, HC = H / 32, CPW = TPW / 2;      // CPW: chunks of the hidden vector a wave produces
+    constexpr int H = 64 * TPW, HC = H / 32, CPW = TPW / 2;      // CPW: chunks of the hidden vector a wave produces
     static_assert(TPW == 2 || TPW == 4, "h = 128 or 256");
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,7 +84,7 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
     gu32x4* rhb = hb + HC * 2 * 64;                             // [HC][2][64]      r (.) h_{t-1}
     gu32x4* xsb = rhb + HC * 2 * 64;                            // [HC][2][64]      this frame's input (the first layer uses KX <= 2 chunks)
     float* biasl = reinterpret_cast<float*>(xsb + HC * 2 * 64); // [3][H] + [16]
-    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * H + 16));      // LAST only
+    const EpilogueLds epi = epilogue_carve(reinterpret_cast<char*>(biasl + 3 * H + 16 + 4));  // LAST only ([3H + 16 .. +4): the pipelined launch's flag)
 
     // the weight stream: buffer loads, lane offset in one VGPR, the operand index in the scalar offset (1 KiB per operand)
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(p.w), (short)0, 0x7fffffff, 0x00020000);
@@ -209,8 +209,16 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
                 for (int hl = 0; hl < 2; ++hl) r.a[(k * TPW + j) * 2 + hl] = wload(TPW * w + j, 2, KX + 2 * m2 + k, hl);
         __builtin_amdgcn_sched_barrier(0);
     };
+    // Both images are always loaded or loading: a phase enters with its first TWO rows requested by the phase before it, every
+    // image is re-requested the moment its MFMAs have been issued -- with the next row of the phase, or of the next phase.
     Row ra, rb;
     load_x(ra, 0);
+    load_x(rb, 1);
+    // layer-pipelined launch, layers above the first: has the layer below already published the NEXT frame?  Asked by one lane a
+    // phase ahead (the answer travels through LDS, so the whole workgroup takes the same branch); if yes the frame's input is
+    // fetched behind barrier #1 and the poll / fetch / barrier at the top of the next frame disappears
+    int* const next_flag = reinterpret_cast<int*>(biasl + 3 * H + 16);
+    bool have_x = false;
 
     for (int t = 0; t < T; ++t) {
         f32x4 am[TPW][3], al[TPW][3];
@@ -221,7 +229,7 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
                 am[j][q] = bl[(q * H + (TPW * w + j) * 16) / 4 + g];
                 al[j][q] = splat4(0.f);
             }
-        if (PIPE && !FIRST) {
+        if (PIPE && !FIRST && !have_x) {
             // frame t of the layer below must have landed (its workgroup runs concurrently on another CU): every wave polls for
             // itself, bounded -- a protocol bug becomes a wrong answer plus an error flag, not a hung GPU (gru_kernels.hip)
             int spins = 0;
@@ -234,6 +242,9 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
             seam_commit();
             __syncthreads();
         }
+        int ahead = 0;
+        if (PIPE && !FIRST && tid == 0 && t + 1 < T)
+            ahead = __hip_atomic_load(p.epi.ready_in + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (lands under the MFMAs below)
         // ---- x-part of r, u, c ----
 #define KWS_G_MMA_X(R_, C_)                                                                             \
         {                                                                                                \
@@ -248,10 +259,10 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
         }
 #pragma nounroll
         for (int c = 0; c < KX; c += 2) {                       // KX is even
-            load_x(rb, c + 1);
             KWS_G_MMA_X(ra, c);
             if (c + 2 < KX) load_x(ra, c + 2); else load_h(ra, 0);
             KWS_G_MMA_X(rb, c + 1);
+            if (c + 3 < KX) load_x(rb, c + 3); else load_h(rb, 1);
         }
 #undef KWS_G_MMA_X
         // ---- recurrent part of r and u ----
@@ -268,14 +279,21 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
         }
 #pragma nounroll
         for (int m = 0; m < HC; m += 2) {                       // HC is even
-            load_h(rb, m + 1);
             KWS_G_MMA_H(ra, m);
-            if (m + 2 < HC) load_h(ra, m + 2); else load_c(ra, 0);      // ... the candidate's first row does not depend on the exchange below
+            if (m + 2 < HC) load_h(ra, m + 2);
+            else {
+                // ... the candidate's rows do not depend on the exchange below.  Pipelined producer: the seam rows of the frame
+                // before must be written through before the counter moves behind barrier #1; draining HERE costs nothing -- all
+                // that is still in flight is the row the next MFMAs wait for anyway -- whereas in front of the barrier it would
+                // also wait for the two candidate rows requested now
+                if (PIPE && !LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                load_c(ra, 0);
+            }
             KWS_G_MMA_H(rb, m + 1);
+            if (m + 3 < HC) load_h(rb, m + 3); else load_c(rb, 1);
         }
 #undef KWS_G_MMA_H
-        // ---- r, u; r (.) h split -> LDS ----
-        f32x4 u[TPW];
+        // ---- r; r (.) h split -> LDS (the u sigmoid waits for the candidate phase: only the update needs it) ----
 #pragma unroll
         for (int jj = 0; jj < CPW; ++jj) {
             f32x4 rh[2];
@@ -285,9 +303,7 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float pr = __builtin_fmaf(al[j][0][e], kGLoInv, am[j][0][e]);
-                    const float pu = __builtin_fmaf(al[j][1][e], kGLoInv, am[j][1][e]);
                     rh[k][e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pr)) * hreg[j][e];
-                    u[j][e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pu));
                 }
             }
             gu32x4 hi, lo;
@@ -295,14 +311,19 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
             rhb[((CPW * w + jj) * 2 + 0) * 64 + lane] = hi;
             rhb[((CPW * w + jj) * 2 + 1) * 64 + lane] = lo;
         }
-        if (PIPE && !LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // last frame's seam rows (half a frame old): written through
+        if (PIPE && !FIRST && tid == 0) *next_flag = ahead > t + 1 ? 1 : 0;
         __syncthreads();              // #1: r (.) h visible; hb and xsb fully consumed
         if (PIPE && !LAST && t > 0 && tid == 0)
-            __hip_atomic_store(p.epi.ready_out + group, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // frames 0..t-1 are out (drained above)
+            __hip_atomic_store(p.epi.ready_out + group, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // frames 0..t-1 are out (every wave drained its stores above)
         // the next frame's input: xsb is free now
         if (FIRST) { mel_commit(); mel_fetch(t + 2); }
         else if (!PIPE) { seam_commit(); seam_fetch(t + 2); }
-        // ---- recurrent part of the candidate ----
+        else {
+            have_x = *next_flag != 0;
+            if (have_x) seam_fetch(t + 1);           // committed behind the candidate MFMAs
+        }
+        // ---- recurrent part of the candidate; the u sigmoid rides in the stream's shadow ----
+        f32x4 u[TPW];
 #define KWS_G_MMA_C(R_, M2_)                                                                            \
         {                                                                                                \
             _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                              \
@@ -315,14 +336,25 @@ __device__ __forceinline__ void gru_f16x3_generic_body(const GruF16Params& p, co
             }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                           \
         }
+        // HC / 2 rows, an even count (HC = 4 or 8); the first pair peeled
+        KWS_G_MMA_C(ra, 0);
+        if (2 < HC / 2) load_c(ra, 2); else load_x(ra, 0);                    // ... the next frame's first x rows
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                u[j][e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(al[j][1][e], kGLoInv, am[j][1][e])));
+        KWS_G_MMA_C(rb, 1);
+        if (3 < HC / 2) load_c(rb, 3); else load_x(rb, 1);
 #pragma nounroll
-        for (int m2 = 0; m2 < HC / 2; m2 += 2) {                // HC / 2 is even (HC = 4 or 8)
-            load_c(rb, m2 + 1);
+        for (int m2 = 2; m2 < HC / 2; m2 += 2) {
             KWS_G_MMA_C(ra, m2);
-            if (m2 + 2 < HC / 2) load_c(ra, m2 + 2); else load_x(ra, 0);      // ... the next frame's first x row
+            if (m2 + 2 < HC / 2) load_c(ra, m2 + 2); else load_x(ra, 0);
             KWS_G_MMA_C(rb, m2 + 1);
+            if (m2 + 3 < HC / 2) load_c(rb, m2 + 3); else load_x(rb, 1);
         }
 #undef KWS_G_MMA_C
+        if (PIPE && !FIRST && have_x) seam_commit();
         // ---- tanh, update, split -> LDS, seam / projection ----
         const unsigned live = t < len_s ? 0xffffffffu : 0u;
         f32x4 fm = splat4(0.f), fl = splat4(0.f);
