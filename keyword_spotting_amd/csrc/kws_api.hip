@@ -332,6 +332,9 @@ inline float f16_value(uint16_t u) {
 inline void f16_split(float v, uint16_t* hi, uint16_t* lo) {
     *hi = f16_rne(v);
     *lo = f16_rne((v - f16_value(*hi)) * 2048.0f);
+#ifdef KWS_EXP_F16_WLO_ZERO      // experiment builds only (tools/build_variant.sh wlo0 -DKWS_EXP_F16_WLO_ZERO): single-piece fp16 WEIGHTS in the
+    *lo = 0;                     // f16x3 kernels -- the hardware check of the rounding model behind the "f16x1" decision
+#endif
 }
 // unit of a hidden vector addressed by (chunk m, lane group g, element j) in the bf16 exchange layout
 inline int bf16_unit(int m, int g, int j) { return 32 * m + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)); }

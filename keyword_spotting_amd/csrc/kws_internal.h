@@ -13,7 +13,7 @@
 // build does not compile.
 #if defined(KWS_FAULT_INJECT) || defined(KWS_ABL_NOFLUSH) || defined(KWS_ABL_NOMEL) || defined(KWS_F16_TIMING) || defined(KWS_FE_TIMING) || \
     defined(KWS_FE_OCC) || defined(KWS_FE_FT) || defined(KWS_FE_SF) || defined(KWS_FE_NOSTAGE) || defined(KWS_FE_NODFT) || defined(KWS_FE_NOMEL) || \
-    defined(KWS_OABL_NODIV) || defined(KWS_OABL_NODOT) || defined(KWS_OVERLAP_MIN_T)
+    defined(KWS_OABL_NODIV) || defined(KWS_OABL_NODOT) || defined(KWS_OVERLAP_MIN_T) || defined(KWS_EXP_F16_WLO_ZERO)
 #ifndef KWS_VARIANT_BUILD
 #error "an experiment switch (KWS_FAULT_INJECT / KWS_ABL_* / KWS_*_TIMING / KWS_FE_* / KWS_OABL_* / KWS_OVERLAP_MIN_T) is defined in a product build: use tools/build_variant.sh"
 #endif
@@ -40,7 +40,12 @@
 #else
 #define KWS_TAG_TIMING ""
 #endif
-#define KWS_VARIANT_TAG "; VARIANT BUILD" KWS_TAG_FAULT KWS_TAG_NOFLUSH KWS_TAG_NOMEL KWS_TAG_TIMING
+#ifdef KWS_EXP_F16_WLO_ZERO
+#define KWS_TAG_WLO KWS_VARIANT_TAG_1(EXP_F16_WLO_ZERO)
+#else
+#define KWS_TAG_WLO ""
+#endif
+#define KWS_VARIANT_TAG "; VARIANT BUILD" KWS_TAG_FAULT KWS_TAG_NOFLUSH KWS_TAG_NOMEL KWS_TAG_TIMING KWS_TAG_WLO
 #else
 #define KWS_VARIANT_TAG ""
 #endif

@@ -192,6 +192,50 @@ def bf16_round(a):
     return r.view(np.float32).reshape(a.shape)
 
 
+def f16_round(a):
+    """fp32 -> fp16 (nearest even) -> fp32: ONE 11-bit piece of the f16x3 split (csrc/gru_f16x3.hip keeps two)."""
+    return np.ascontiguousarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def gru_forward_rounded(w, mel, round_w, round_x, state=None, seq_len=None):
+    """The rounding model of gru_forward_bf16 with the two roundings chosen separately: round_w on every weight matrix,
+    round_x on every matmul input (x, h, r*h, top-layer h).  Used to price operand precisions BEFORE a kernel is written
+    (tests/test_oracle_gru.py::test_what_single_piece_fp16_operands_would_cost): with bf16_round for both it IS
+    gru_forward_bf16, whose predictions the bf16 HIP stack reproduces (tests/test_gpu_bf16.py)."""
+    mel = np.asarray(mel, np.float32)
+    b, t_len, _ = mel.shape
+    nl = len(w["layers"])
+    hdim = w["Wfc"].shape[0]
+    if state is None:
+        state = np.zeros((nl, b, hdim), np.float32)
+    h = [np.array(state[l], np.float64) for l in range(nl)]
+    if seq_len is None:
+        seq_len = np.full(b, t_len, np.int64)
+    seq_len = np.asarray(seq_len)
+    wq = [dict(Wg=round_w(l["Wg"]).astype(np.float64), Wc=round_w(l["Wc"]).astype(np.float64),
+               bg=l["bg"].astype(np.float64), bc=l["bc"].astype(np.float64)) for l in w["layers"]]
+    wfc = round_w(w["Wfc"]).astype(np.float64)
+    top = np.zeros((b, t_len, hdim), np.float64)
+    for t in range(t_len):
+        live = (t < seq_len)[:, None]
+        x = round_x(mel[:, t, :]).astype(np.float64)
+        for l in range(nl):
+            lay = wq[l]
+            i_l = x.shape[1]
+            hb = round_x(h[l].astype(np.float32)).astype(np.float64)
+            g = _sigmoid(x @ lay["Wg"][:i_l] + hb @ lay["Wg"][i_l:] + lay["bg"])
+            r, u = g[:, :hdim], g[:, hdim:]
+            rh = round_x((r * h[l]).astype(np.float32)).astype(np.float64)
+            c = np.tanh(x @ lay["Wc"][:i_l] + rh @ lay["Wc"][i_l:] + lay["bc"])
+            hn = u * h[l] + (1.0 - u) * c
+            h[l] = np.where(live, hn, h[l])
+            x = round_x(h[l].astype(np.float32)).astype(np.float64)
+            if l == nl - 1:
+                top[:, t, :] = np.where(live, hn, 0.0)
+    logits = round_x(top.reshape(-1, hdim).astype(np.float32)).astype(np.float64) @ wfc + w["bfc"].astype(np.float64)
+    return logits.reshape(b, t_len, -1), np.stack(h)
+
+
 def gru_forward_bf16(w, mel, state=None, seq_len=None):
     mel = np.asarray(mel, np.float32)
     b, t_len, _ = mel.shape
