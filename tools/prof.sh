@@ -46,3 +46,6 @@ else grep -v "amdgpu.ids\|rocprofv3\|^[EWI][0-9]\{8\}\|^$" $OUT/trace_bench.log 
 # first token still matches its own csrc_hash(); the second is the sha1 of the libkws_amd.so the profiled process loaded.
 python3 -c "import sys, hashlib; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import bench; from keyword_spotting_amd import _lib; print(bench.csrc_hash(), hashlib.sha1(open(_lib.LIB_PATH, 'rb').read()).hexdigest()[:16])" > $OUT/commit/${TAG}_source_hash.txt \
   || fail "could not stamp the source hash"
+# the raw traces are large (the serving run alone leaves > 100 MB of kernel records) and gpurun copies back 64 MiB at most:
+# only the summaries travel
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
