@@ -3,17 +3,26 @@
 // 202-284; TF-1.x GRUCell), same boundary, same tolerances (logits within 1e-4 of the fp64 oracle; observed ~3e-6).
 //
 // Every matmul operand is split into two fp16 numbers that together carry 22 mantissa bits,
-//     v = hi + 2^-11 lo,   hi = fp16(v),   lo = fp16((v - hi) * 2^11)        (both round-to-nearest-even),
-// weights once at kws_create, activations on the fly (per pair of values: one v_cvt_pk_f16_f32 for hi, then per value a
-// v_mul_f32 by 2^11 and a v_fma_mixlo/hi_f16 that reads the fp16 half of hi and writes the rounded fp16 half of lo in place
-// -- bit-identical to subtract, scale, convert).  A product then needs THREE v_mfma_f32_16x16x32_f16
+//     v = hi + lo,   hi = fp16(v),   lo = fp16(v - hi)                        (both round-to-nearest-even),
+// weights once at kws_create, activations on the fly (per pair of values: one v_cvt_pk_f16_f32 for hi, then per value ONE
+// v_fma_mixlo/hi_f16 that reads the fp16 half of hi, multiplies it by the inline constant -1.0, adds the value and writes the
+// rounded fp16 half of lo in place -- bit-identical to subtract, convert).  A product then needs THREE v_mfma_f32_16x16x32_f16
 // instead of eight v_mfma_f32_16x16x4_f32 of twice the duration (~51 matrix-pipe cycles per 32 k instead of 256):
-//     main += Wh Xh          lo += Wl Xh + Wh Xl          result = main + 2^-11 lo        (fp32 accumulators)
-// fp16 x fp16 products are exact in fp32; the dropped term Wl Xl 2^-22 is below fp32's own rounding of the product.  The
-// 2^11 scale keeps the lo piece of every value with |v| >= 2^-14 in fp16's normal range; below that hi is itself subnormal
-// and lo smaller still, and the path relies on the matrix pipe multiplying fp16 subnormals exactly (it does on gfx950:
-// tests/test_gpu_parity.py feeds mel magnitudes down to 1e-6, whose pieces are all subnormal; kws_selftest runs the same kernels).  bf16
-// splits would need 3 + 3 pieces and six products for the same 24 bits; fp16's 11-bit pieces need two and three.
+//     acc += Wh Xh + Wl Xh + Wh Xl                                              (ONE fp32 accumulator)
+// fp16 x fp16 products are exact in fp32; the dropped term Wl Xl is below fp32's own rounding of the product.  Round 6: the
+// lo pieces sit at their OWN magnitude.  Rounds 4-5 scaled them by 2^11 (to keep them in fp16's normal range) and therefore
+// kept a second accumulator per product, folded in with an fma per value before every activation -- 24 + 16 VALU
+// instructions per frame and wave and 48 registers that the in-order-issue-bound frame loop could not spare (the last-layer
+// kernels sat at 512 registers with 6-19 spills; now 468-504 and none; -3 % per 4096 x 300 step, -5 % per 16384 x 22-frame call).
+// Unscaled, a lo piece below 2^-14 is an fp16 subnormal with absolute precision 2^-25: a value keeps max(2^-23 |v|, 2^-25), i.e.
+// fp32's own rounding down to |v| = 1/4 and a 3e-8 absolute floor below -- nothing against the 1e-4 bar for hidden values in
+// [-1, 1] and weights of O(0.1) (max |dlogit| against the fp32 kernels 6.4e-6, as before; every stream's token sequence identical).
+// The path relies on the matrix pipe multiplying fp16 subnormals exactly (it does on gfx950: tests/test_gpu_parity.py feeds
+// mel magnitudes down to 1e-6, whose pieces are all subnormal; kws_selftest runs the same kernels).  The ONE exception is the mel
+// frame: pre-scaled by 2^-8 it is small against its weights (scaled by 2^8), where a 2^-25 floor would cost 1e-5 on a
+// pre-activation -- so the first layer's x-part keeps the 2^11-scaled lo pieces (input and weights) and lo accumulators of its own,
+// folded in once per gate.  bf16 splits would need 3 + 3 pieces and six products for the same 24 bits; fp16's 11-bit pieces need
+// two and three.
 // Range: |hidden| <= 1; weights must be < 64 in magnitude (kws_create checks); mel is pre-scaled by 2^-8 (and the
 // x-part weights of the first layer by 2^8, both exact), so |mel| up to 1.6e7 is represented and larger values saturate.
 // The exponent scales of the activations (sigmoid: -log2 e, tanh: 2 log2 e) are folded into the packed weights and biases,
@@ -28,7 +37,7 @@
 //                          4-operand register sets
 //
 // The frame loop is a static schedule.  Per frame a wave issues 147 (upper layers) / 111 (first layer) MFMAs of ~17
-// cycles and ~170 VALU instructions; an MFMA runs in the matrix pipe while the wave issues VALU work of its own, but issue
+// cycles and ~130 (first layer: ~155) VALU instructions; an MFMA runs in the matrix pipe while the wave issues VALU work of its own, but issue
 // is in order, so the two only overlap when they ALTERNATE in the instruction stream.  The recurrence fixes a critical
 // chain  gates_h MFMAs -> r sigmoid -> r(.)h split -> LDS -> barrier -> cand_h MFMAs -> tanh, update, split -> LDS ->
 // barrier;  the next frame's x-part (72 / 36 MFMAs, independent of the recurrence) is the filler that is woven, one MFMA
@@ -62,6 +71,7 @@ __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// the mel input: lo scaled by 2^11 (its own accumulators in the first layer: see the header)
 __device__ __forceinline__ void split2(f32x2 x, unsigned& hi, unsigned& lo) {
     const f16x2 h = __builtin_convertvector(x, f16x2);
     const f32x2 r = (x - __builtin_convertvector(h, f32x2)) * kLoScale;
@@ -69,17 +79,24 @@ __device__ __forceinline__ void split2(f32x2 x, unsigned& hi, unsigned& lo) {
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
+// hidden values (|v| <= 1): lo = fp16(v - hi), UNSCALED
+__device__ __forceinline__ void split2u(f32x2 x, unsigned& hi, unsigned& lo) {
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 // the wave's two C tiles -> its chunk of the next B operand, (hi, lo)
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
     unsigned h[4], l[4];
-    split2((f32x2){a[0], a[1]}, h[0], l[0]);
-    split2((f32x2){a[2], a[3]}, h[1], l[1]);
-    split2((f32x2){b[0], b[1]}, h[2], l[2]);
-    split2((f32x2){b[2], b[3]}, h[3], l[3]);
+    split2u((f32x2){a[0], a[1]}, h[0], l[0]);
+    split2u((f32x2){a[2], a[3]}, h[1], l[1]);
+    split2u((f32x2){b[0], b[1]}, h[2], l[2]);
+    split2u((f32x2){b[2], b[3]}, h[3], l[3]);
     hi = (u32x4){h[0], h[1], h[2], h[3]};
     lo = (u32x4){l[0], l[1], l[2], l[3]};
 }
-__device__ __forceinline__ f32x4 combine(const f32x4& m, const f32x4& l) { return m + l * kLoInv; }
 
 // nothing is scheduled across this point: the weave below stays as written
 __device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
@@ -296,8 +313,8 @@ gru_layer_f16x3(const GruF16Params p) {
 
     // The activation streams are single instructions; a 32-bit literal doubles an instruction's size (8 bytes), and a lone
     // wave per SIMD is fed instructions at a limited rate, so the constants live in scalar registers (VOP2 encodings, 4 bytes).
-    float cLoInv = kLoInv, cLoScale = kLoScale, cNegLoScale = -kLoScale, cNegTwo = -2.0f;
-    asm volatile("" : "+s"(cLoInv), "+s"(cLoScale), "+s"(cNegLoScale), "+s"(cNegTwo));
+    float cLoInv = kLoInv, cNegTwo = -2.0f;
+    asm volatile("" : "+s"(cLoInv), "+s"(cNegTwo));
 
     for (int group = blockIdx.x; group < n_groups; group += gridDim.x) {
         const int b_raw = group * kStreamsPerGroup + s;
@@ -365,7 +382,7 @@ gru_layer_f16x3(const GruF16Params p) {
             if constexpr (i < NE0) {
                 constexpr int q = i / 2, j = i % 2;
                 am[PN][j][q] = bl[(q * H + (2 * w + j) * 16) / 4 + g];
-                al[PN][j][q] = splat4(0.f);
+                if constexpr (FIRST) al[PN][j][q] = splat4(0.f);
             } else if constexpr (i < NE0 + NE1) {
                 constexpr int c = (i - NE0) / 2, hl = (i - NE0) % 2;
                 xb[c][hl] = as_f16x8(xsb[xs_off[PN] + (c * 2 + hl) * 64]);
@@ -388,7 +405,9 @@ gru_layer_f16x3(const GruF16Params p) {
             f16x8 W;
             if constexpr (place == kInLds) W = wtmp[k & 1][j][sweep == 1 ? 1 : 0];
             else W = wx[j][q][c][sweep == 1 ? 1 : 0];
-            if constexpr (sweep == 0) am[PN][j][q] = mfma_f16(W, B, am[PN][j][q]);
+            // the first layer's x-part is the mel frame, whose lo piece (and the lo piece of its weights) carries the 2^11 scale:
+            // those cross terms have accumulators of their own; everything else goes into ONE accumulator
+            if constexpr (sweep == 0 || !FIRST) am[PN][j][q] = mfma_f16(W, B, am[PN][j][q]);
             else al[PN][j][q] = mfma_f16(W, B, al[PN][j][q]);
             if constexpr (place == kInLds && r % 6 == 5 && k + 2 < NG) {       // this group's register set is free again
 #pragma unroll
@@ -410,8 +429,7 @@ gru_layer_f16x3(const GruF16Params p) {
             constexpr int m = i / 12, r = i % 12, sweep = r / 4, j = (r % 4) / 2, q = r % 2;
             const f16x8 B = hB[m & 1][sweep == 2 ? 1 : 0];
             const f16x8 W = wh[j][q][m][sweep == 1 ? 1 : 0];
-            if constexpr (sweep == 0) am[PC][j][q] = mfma_f16(W, B, am[PC][j][q]);
-            else al[PC][j][q] = mfma_f16(W, B, al[PC][j][q]);
+            am[PC][j][q] = mfma_f16(W, B, am[PC][j][q]);
             if constexpr (r == 11 && m + 2 < 4) hread(hb, m + 2, m & 1);
         };
         auto Cm = [&](auto pc_, auto i_) {
@@ -419,8 +437,7 @@ gru_layer_f16x3(const GruF16Params p) {
             constexpr int m = i / 6, r = i % 6, sweep = r / 2, j = r % 2;
             const f16x8 B = hB[m & 1][sweep == 2 ? 1 : 0];
             const f16x8 W = wh[j][2][m][sweep == 1 ? 1 : 0];
-            if constexpr (sweep == 0) am[PC][j][2] = mfma_f16(W, B, am[PC][j][2]);
-            else al[PC][j][2] = mfma_f16(W, B, al[PC][j][2]);
+            am[PC][j][2] = mfma_f16(W, B, am[PC][j][2]);
             if constexpr (r == 5 && m + 2 < 4) hread(rhb, m + 2, m & 1);
         };
         // R, U, Cc: the activation arithmetic, ONE scalar VALU instruction per element (packed fp32 instructions beside MFMAs
@@ -428,55 +445,55 @@ gru_layer_f16x3(const GruF16Params p) {
         // that no element waits for the one before it: stage-major order.  The fp16 pack stages have four elements.
         // Split of a value v with hi already packed:  lo16 = fp16(fma(hi16 as f32, -2^11, v * 2^11))  -- v_fma_mixlo/hi_f16 reads
         // the fp16 half directly and writes the rounded fp16 half in place (bit-identical to the subtract-scale-convert form).
-        float va[8], vb[8], uu[8];
+        float va[8], vb[8], uu[8];      // (vb: the candidate path's h - c)
         unsigned phi[4], plo[4] = {0u, 0u, 0u, 0u};
-        auto mix_lo = [&](auto un_, float m) {
+        auto mix_lo = [&](auto un_, float m) {          // lo16 = fp16(m - hi16): the value's own hi half, times the inline constant -1.0, plus the value
             constexpr int un = decltype(un_)::value;
             const unsigned hi = phi[un >> 1];
-            const float nk = cNegLoScale;
             unsigned d = plo[un >> 1];
-            if constexpr ((un & 1) == 0) asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi), "s"(nk), "v"(m));
-            else asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi), "s"(nk), "v"(m));
+            if constexpr ((un & 1) == 0) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi), "v"(m));
+            else asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi), "v"(m));
             plo[un >> 1] = d;
         };
+        constexpr int S0 = FIRST ? 1 : 0;             // elementwise stages in front of the exp: the first layer folds its x-part's lo accumulators in
         auto R = [&](auto pc_, auto i_) {
             constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value;
-            // stages: 0 fma, 1 exp, 2 add, 3 rcp, 4 mul h | 5 pack hi (4) | 6 scale, 7 lo half
-            constexpr int st = i < 40 ? i / 8 : i < 44 ? 5 : 6 + (i - 44) / 8;
-            constexpr int un = i < 40 ? i % 8 : i < 44 ? i - 40 : (i - 44) % 8;
+            // stages: [0 fma: first layer] 1 exp, 2 add, 3 rcp, 4 mul h | 5 pack hi (4) | 7 lo half
+            constexpr int NE8 = (S0 + 4) * 8;
+            constexpr int st = i < NE8 ? i / 8 + (1 - S0) : i < NE8 + 4 ? 5 : 7;
+            constexpr int un = i < NE8 ? i % 8 : i < NE8 + 4 ? i - NE8 : (i - NE8 - 4) % 8;
             if constexpr (st == 5) phi[un] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){va[2 * un], va[2 * un + 1]}, f16x2));
             else {
                 constexpr int j = un >> 2, e = un & 3;
                 if constexpr (st == 0) va[un] = __builtin_fmaf(al[PC][j][0][e], cLoInv, am[PC][j][0][e]);
-                else if constexpr (st == 1) va[un] = __builtin_amdgcn_exp2f(va[un]);
+                else if constexpr (st == 1) va[un] = __builtin_amdgcn_exp2f(FIRST ? va[un] : am[PC][j][0][e]);
                 else if constexpr (st == 2) va[un] = va[un] + 1.0f;
                 else if constexpr (st == 3) va[un] = __builtin_amdgcn_rcpf(va[un]);
                 else if constexpr (st == 4) va[un] = va[un] * hreg[j][e];
-                else if constexpr (st == 6) vb[un] = va[un] * cLoScale;
-                else mix_lo(std::integral_constant<int, un>{}, vb[un]);
+                else mix_lo(std::integral_constant<int, un>{}, va[un]);
             }
         };
-        constexpr int NR = 5 * 8 + 4 + 2 * 8;         // 60
+        constexpr int NR = (S0 + 4) * 8 + 4 + 8;      // 44 (52 in the first layer)
         auto U = [&](auto pc_, auto i_) {
-            constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value, st = i / 8, un = i % 8, j = un >> 2, e = un & 3;
+            constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value, st = i / 8 + (1 - S0), un = i % 8, j = un >> 2, e = un & 3;
             if constexpr (st == 0) uu[un] = __builtin_fmaf(al[PC][j][1][e], cLoInv, am[PC][j][1][e]);
-            else if constexpr (st == 1) uu[un] = __builtin_amdgcn_exp2f(uu[un]);
+            else if constexpr (st == 1) uu[un] = __builtin_amdgcn_exp2f(FIRST ? uu[un] : am[PC][j][1][e]);
             else if constexpr (st == 2) uu[un] = uu[un] + 1.0f;
             else uu[un] = __builtin_amdgcn_rcpf(uu[un]);
         };
-        constexpr int NU = 4 * 8;                     // 32
+        constexpr int NU = (S0 + 3) * 8;              // 24 (32 in the first layer)
         unsigned live = 0u;
-        constexpr int NCS = MASKED ? 8 : 7;           // elementwise stages of the candidate path before the split
+        constexpr int NCS = S0 + 6 + (MASKED ? 1 : 0);           // elementwise stages of the candidate path before the split
         auto Cc = [&](auto pc_, auto i_) {
             constexpr int PC = decltype(pc_)::value, i = decltype(i_)::value;
-            // stages: 0 fma, 1 exp, 2 add, 3 rcp, 4 fma (tanh), 5 sub, 6 fma (update) [, 7 select: MASKED] | pack hi (4) | scale, lo half
-            constexpr int st = i < NCS * 8 ? i / 8 : i < NCS * 8 + 4 ? 100 : 101 + (i - NCS * 8 - 4) / 8;
+            // stages: [0 fma: first layer] 1 exp, 2 add, 3 rcp, 4 fma (tanh), 5 sub, 6 fma (update) [, 7 select: MASKED] | pack hi (4) | lo half
+            constexpr int st = i < NCS * 8 ? i / 8 + (1 - S0) : i < NCS * 8 + 4 ? 100 : 102;
             constexpr int un = i < NCS * 8 ? i % 8 : i < NCS * 8 + 4 ? i - NCS * 8 : (i - NCS * 8 - 4) % 8;
             if constexpr (st == 100) phi[un] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){hreg[un >> 1][2 * (un & 1)], hreg[un >> 1][2 * (un & 1) + 1]}, f16x2));
             else {
                 constexpr int j = un >> 2, e = un & 3;
                 if constexpr (st == 0) va[un] = __builtin_fmaf(al[PC][j][2][e], cLoInv, am[PC][j][2][e]);
-                else if constexpr (st == 1) va[un] = __builtin_amdgcn_exp2f(va[un]);
+                else if constexpr (st == 1) va[un] = __builtin_amdgcn_exp2f(FIRST ? va[un] : am[PC][j][2][e]);
                 else if constexpr (st == 2) va[un] = va[un] + 1.0f;
                 else if constexpr (st == 3) va[un] = __builtin_amdgcn_rcpf(va[un]);
                 else if constexpr (st == 4) va[un] = __builtin_fmaf(va[un], cNegTwo, 1.0f);                     // tanh
@@ -485,11 +502,10 @@ gru_layer_f16x3(const GruF16Params p) {
                     if constexpr (MASKED) va[un] = __builtin_fmaf(uu[un], vb[un], va[un]);                      // c + u (h - c)
                     else hreg[j][e] = __builtin_fmaf(uu[un], vb[un], va[un]);
                 } else if constexpr (st == 7) hreg[j][e] = bitsel(live, va[un], hreg[j][e]);                  // copy-through past seq_len
-                else if constexpr (st == 101) vb[un] = hreg[j][e] * cLoScale;
-                else mix_lo(std::integral_constant<int, un>{}, vb[un]);
+                else mix_lo(std::integral_constant<int, un>{}, hreg[j][e]);
             }
         };
-        constexpr int NC = NCS * 8 + 4 + 2 * 8;       // 76 (84 with the mask)
+        constexpr int NC = NCS * 8 + 4 + 8;           // 60 (68 in the first layer; + 8 with the mask)
         // FIRST: the next-but-one mel frame (one dwordx4 per lane, streams 4w..4w+3) -> scaled, clamped, split, scattered into
         // its xsb slot; 24 scalar VALU elements that ride under the G MFMAs, then the two LDS stores
         float mv[4], mr[4];
@@ -639,7 +655,7 @@ gru_layer_f16x3(const GruF16Params p) {
                 fl2 = mfma_f16(wfc[0], as_f16x8(hlo), fl2);
                 pin();
                 run<XW2, XR + XW1 + XB1 + XC>([&](auto i_) { X(pn, i_); });     // while the h store lands and the projection drains
-                const f32x4 accf = combine(fm, fl2);
+                const f32x4 accf = fm + fl2;
                 if (g < 2) *reinterpret_cast<f32x4*>(epi.pstage + (w * 16 + s) * 8 + 4 * g) = accf;
             } else {
                 run<XW2, XR + XW1 + XB1 + XC>([&](auto i_) { X(pn, i_); });

@@ -336,6 +336,15 @@ inline void f16_split(float v, uint16_t* hi, uint16_t* lo) {
     *lo = 0;                     // f16x3 kernels -- the hardware check of the rounding model behind the "f16x1" decision
 #endif
 }
+// ... and with the lo piece at its own magnitude: v = hi + lo.  Below 2^-14 the piece is an fp16 subnormal (absolute precision
+// 2^-25): the value keeps max(2^-23 |v|, 2^-25) -- fp32's own rounding down to |v| = 1/4, a 3e-8 absolute floor below that
+inline void f16_split_unscaled(float v, uint16_t* hi, uint16_t* lo) {
+    *hi = f16_rne(v);
+    *lo = f16_rne(v - f16_value(*hi));
+#ifdef KWS_EXP_F16_WLO_ZERO
+    *lo = 0;
+#endif
+}
 // unit of a hidden vector addressed by (chunk m, lane group g, element j) in the bf16 exchange layout
 inline int bf16_unit(int m, int g, int j) { return 32 * m + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)); }
 
@@ -556,7 +565,11 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
                                 const float act = gq == 2 ? 2.0f * 1.4426950408889634f : -1.4426950408889634f;
                                 const float v = ok ? scale * (act * wq(Wg, Wc, H, gq, row, n * 16 + i)) : 0.f;
                                 uint16_t hi, lo;
-                                f16_split(v, &hi, &lo);
+                                // the register-resident kernels (gru_f16x3.hip) keep ONE accumulator per product: lo pieces unscaled,
+                                // except the first layer's x-part, which meets the mel frame's 2^11-scaled lo piece; the streaming
+                                // kernels (gru_f16x3_generic.hip) keep main / lo accumulators and scaled lo pieces throughout
+                                if (m->f16_generic || (l == 0 && c < kx)) f16_split(v, &hi, &lo);
+                                else f16_split_unscaled(v, &hi, &lo);
                                 const size_t base = (((size_t)(n * 3 + gq) * kc + c) * 2) * 64;
                                 dst[(base + lane) * 8 + j] = hi;
                                 dst[(base + 64 + lane) * 8 + j] = lo;
@@ -571,7 +584,9 @@ int kws_create(const kws_config* cfg, const void* weights_blob, size_t nbytes, k
                 for (int j = 0; j < 8; ++j) {
                     const int g = lane >> 4, i = lane & 15;
                     uint16_t hi, lo;
-                    f16_split(i < C ? Wfc[(size_t)bf16_unit(c, g, j) * C + i] : 0.f, &hi, &lo);
+                    const float v = i < C ? Wfc[(size_t)bf16_unit(c, g, j) * C + i] : 0.f;
+                    if (m->f16_generic) f16_split(v, &hi, &lo);
+                    else f16_split_unscaled(v, &hi, &lo);
                     dst[(((size_t)c * 2 + 0) * 64 + lane) * 8 + j] = hi;
                     dst[(((size_t)c * 2 + 1) * 64 + lane) * 8 + j] = lo;
                 }
