@@ -59,6 +59,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 tot = 0
 tot += repeat_stream(n)
 tot += repeat("pipelined 4xGRU h=256 (configs[4])", get_config(n_mel=60, hidden_size=256, num_layers=4), 1024, 60, n)
+tot += repeat("pipelined f16x3 4xGRU h=256 (configs[4])", get_config(n_mel=60, hidden_size=256, num_layers=4, precision="f16x3"), 1024, 60, n)
+tot += repeat("pipelined f16x3 4xGRU h=256, 3 groups", get_config(n_mel=60, hidden_size=256, num_layers=4, precision="f16x3"), 40, 33, n)
+tot += repeat("f16x3 h=256 per-layer launches, ragged", get_config(n_mel=60, hidden_size=256, num_layers=4, precision="f16x3"), 1100, 23, n)
 tot += repeat("pipelined 2xGRU h=128 generic", get_config(), 2048, 60, n, kernel="generic")
 tot += repeat("pipelined 8xGRU h=64", get_config(hidden_size=64, num_layers=8), 512, 60, n)
 tot += repeat("int8 graph", get_config(precision="int8"), 4096, 40, n)
