@@ -127,3 +127,49 @@ def test_managers_share_the_models_staging_block_and_own_only_their_state():
     for mgr in more + [first]:
         mgr.close()
     m.close()
+
+
+def test_stream_server_periods_equal_plain_managers_and_pacing_reports():
+    """keyword_spotting_amd.serving: M managers round-robin on the server's handles / HIP streams give, period by period, the hits
+    of M plain StreamManagers fed one after the other on the default stream; run_paced feeds in real time and reports the
+    period compute times and deadline misses."""
+    from keyword_spotting_amd import get_config
+    from keyword_spotting_amd.detector import StreamManager
+    from keyword_spotting_amd.frontend import MelFrontend
+    from keyword_spotting_amd.rnn_ctc import DeployModel
+    from keyword_spotting_amd.serving import StreamServer, run_paced
+    cfg = get_config(precision="f16x3")
+    fe = MelFrontend(cfg)
+    rng = np.random.default_rng(8300)
+    w, label = _emitting(cfg, fe, rng)
+    s, m_count, periods = 48, 5, 7
+    pcm = [[torch.from_numpy(rng.integers(-6000, 6000, (s, 3600)).astype(np.int16)).cuda() for _ in range(m_count)] for _ in range(periods)]
+    torch.cuda.synchronize()
+    server = StreamServer(cfg, weights=w, streams_per_manager=s, handles=2, label=label, window_chunks=4).resize(m_count)
+    assert server.n_streams == s * m_count and len(server.models) == 2
+    got = []
+    for p in range(periods):
+        assert server.feed_period(lambda k: pcm[p][k]) == m_count
+        got.append(server.hits().cpu())
+    assert server.launches_per_chunk() == 3                     # gate + front-end, two GRU layers with the window step inside the second
+    models = [DeployModel(cfg, w) for _ in range(m_count)]
+    plain = [StreamManager(models[k], batch=s, label=label, window_chunks=4) for k in range(m_count)]
+    total = 0
+    for p in range(periods):
+        want = torch.stack([plain[k].feed_pcm(pcm[p][k], fe).clone() for k in range(m_count)]).cpu()
+        assert torch.equal(got[p], want), p
+        total += int(want.sum())
+    assert total > 0
+    for k in range(m_count):
+        assert torch.equal(server.managers[k].state, plain[k].state)
+    # shrinking and growing keeps the survivors' state; pacing: 5 periods of 20 ms
+    server.resize(3)
+    assert server.n_streams == 3 * s and torch.equal(server.managers[2].state, plain[2].state)
+    server.resize(4)
+    rep = run_paced(server, lambda p, k: pcm[p % periods][k], periods=5, period_s=0.02)
+    assert rep["periods"] == 5 and rep["deadline_misses"] == 0 and 0 < rep["compute_ms_p50"] <= rep["compute_ms_max"] < 20.0
+    for m in plain:
+        m.close()
+    for m in models:
+        m.close()
+    server.close()
