@@ -457,9 +457,9 @@ def secondary_lines(device):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_serve
         for prec in ("fp32", "f16x3", "bf16"):
-            out["sustained real-time, N distinct streams, %s" % prec] = bench_serve.sustained_streams(device, prec, periods=40, max_attempts=2)
+            out["sustained real-time, N distinct streams, %s" % prec] = bench_serve.sustained_streams(device, prec, periods=40, max_attempts=3)
         out["sustained real-time, N distinct streams, fp32, host-fed (pinned int16 over PCIe, copy streams overlapped)"] = \
-            bench_serve.sustained_streams(device, "fp32", periods=40, max_attempts=2, host_fed=True)
+            bench_serve.sustained_streams(device, "fp32", periods=40, max_attempts=3, host_fed=True)
     except Exception as exc:
         out["sustained real-time, N distinct streams"] = {"error": repr(exc)}
     return out
